@@ -1,0 +1,136 @@
+/* ishara_hip.h — C ABI of libishara_hip.so: the MI355X (gfx950) hot path of the Ishara
+ * ASL-fingerspelling recogniser (Conv1D -> Squeezeformer -> Conformer CTC encoder).
+ *
+ * The reference (tanmayrainanda/ishara) has no native code and no FFI: its hot path is the
+ * Keras object built by get_model(...) in `Test Notebooks/conv-hybrid-model.ipynb` and
+ * driven by model.fit.  Each entry point below names the reference construct it replaces.
+ *
+ * Conventions: every function returns 0 on success, <0 on error (ishara_last_error() gives
+ * a thread-local message).  The CALLER owns every buffer (parameters, gradients, optimizer
+ * slots, workspace, inputs, outputs; torch-ROCm tensors in the Python host).  The library
+ * allocates no device memory, never synchronises, and launches everything on the hipStream_t
+ * it is given.  A handle is bound to the device current at ishara_bind() and is not
+ * thread-safe: one handle per rank.
+ */
+#ifndef ISHARA_HIP_H
+#define ISHARA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ishara_model ishara_model;
+typedef void* ishara_stream;              /* hipStream_t */
+
+enum { ISHARA_F32 = 0, ISHARA_BF16 = 1 };
+
+/* get_model(...) kwargs — conv-hybrid-model.ipynb c7:1-11 — plus the notebook globals the
+ * function closes over (INPUT_SHAPE c3:119, len(char_to_num) c1:7) and the variant knobs
+ * of the sibling notebooks (top_conv width, per-family expansion). 0 / negative = default. */
+typedef struct ishara_config {
+    int32_t dim;
+    int32_t num_conv_squeeze_blocks;
+    int32_t num_conv_conform_blocks;
+    int32_t num_kernel_sizes;
+    int32_t kernel_sizes[8];
+    int32_t num_conv_per_block;
+    float   dropout_rate;
+    int32_t num_heads;
+    int32_t expansion_factor;
+    int32_t transformer_kernel_size;
+    int32_t frames;                 /* T  = INPUT_SHAPE[0] */
+    int32_t features;               /* F  = INPUT_SHAPE[1] */
+    int32_t num_classes;            /* 60; blank = num_classes-1 */
+    int32_t top_dim;                /* 0 -> 2*dim (c7:61) */
+    int32_t squeeze_expansion;      /* 0 -> expansion_factor */
+    int32_t conformer_expansion;    /* 0 -> expansion_factor */
+    float   head_dropout;           /* c7:62: 0.4 */
+    float   conformer_attn_dropout; /* c5:312 default 0.1 */
+    int32_t dtype;                  /* ISHARA_F32 | ISHARA_BF16: activation storage + MFMA input type */
+    int32_t max_batch;              /* workspace is planned for this many clips */
+    int32_t max_label_len;          /* MAX_PHRASE_LENGTH = 64 (c1:28) */
+    int32_t attn_impl;              /* 0 lane-split VALU, 1 MFMA (bf16 only) */
+} ishara_config;
+
+const char* ishara_last_error(void);
+
+/* tf.keras.Model construction (c7:12-65).  Host only: touches no GPU. */
+int  ishara_create(const ishara_config* cfg, ishara_model** out);
+void ishara_destroy(ishara_model* m);
+
+/* model.summary() / model.weights (c7:83): flat fp32 parameter buffer layout.  Trainable
+ * entries come first (offsets [0, trainable)), BatchNorm moving statistics after them, so
+ * the gradient buffer [0, trainable) is one contiguous all-reduce bucket. */
+int64_t ishara_param_total(const ishara_model* m);
+int64_t ishara_param_trainable(const ishara_model* m);
+int32_t ishara_param_entries(const ishara_model* m);
+int  ishara_param_info(const ishara_model* m, int32_t i, const char** name, int32_t* ndim,
+                       int64_t shape[2], int64_t* offset, int32_t* trainable);
+int64_t ishara_workspace_bytes(const ishara_model* m);
+
+/* Bind caller-owned device buffers.  params/grads: ishara_param_total floats (grads only
+ * uses the trainable prefix); opt_m/opt_v/opt_slow: ishara_param_trainable floats each
+ * (may be NULL for inference); workspace: ishara_workspace_bytes bytes, 256-B aligned. */
+int ishara_bind(ishara_model* m, float* params, float* grads, float* opt_m, float* opt_v,
+                float* opt_slow, void* workspace, int64_t workspace_bytes);
+/* Re-derive the MFMA-typed weight shadows after the caller wrote `params` (load_weights). */
+int ishara_sync_weights(ishara_model* m, ishara_stream s);
+
+/* model(x, training=...) — c7:82, c9:15, c13:17.  x [B,T,F] f32, logits [B,T,C] f32. */
+int ishara_forward(ishara_model* m, const float* x, int32_t B, float* logits, int32_t training,
+                   uint32_t seed, ishara_stream s);
+/* CTCLoss (c6:1-13) + tape.gradient of Keras train_step (c12).  Uses the activations saved
+ * by the last ishara_forward(training=1).  labels [B,L] int64 padded with blank.
+ * loss (device scalar) = mean_b nll_b; gradients of loss*loss_scale fill grads[0,trainable). */
+int ishara_loss_backward(ishara_model* m, const float* logits, const int64_t* labels, int32_t B,
+                         float* loss, float* nll, float loss_scale, ishara_stream s);
+/* Lookahead(RectifiedAdam(sma_threshold=4), sync_period=5) apply_gradients — c7:68-69. */
+int ishara_optimizer_step(ishara_model* m, float lr, float weight_decay, ishara_stream s);
+int32_t ishara_optimizer_iterations(const ishara_model* m);
+int ishara_optimizer_set_iterations(ishara_model* m, int32_t it);
+
+/* decode_phrase (c8:4-12) for a batch: out_idx [B,T] int32 (-1 padded), out_len [B]. */
+int ishara_greedy_decode(const float* logits, int32_t B, int32_t T, int32_t C, int32_t blank,
+                         int32_t* out_idx, int32_t* out_len, ishara_stream s);
+/* tf.nn.ctc_loss alone: nll [B]; dlogits [B,T,C] may be NULL; ws = ishara_ctc_workspace_bytes. */
+int64_t ishara_ctc_workspace_bytes(int32_t B, int32_t T, int32_t L);
+int ishara_ctc_loss(const float* logits, const int64_t* labels, int32_t B, int32_t T, int32_t C,
+                    int32_t L, int32_t blank, float* nll, float* dlogits, float grad_scale,
+                    void* ws, ishara_stream s);
+/* The dropout mask the kernels draw for (seed, site): out [rows, cols] f32 (0 or 1/(1-rate)). */
+int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, int32_t cols, float rate,
+                        float* out, ishara_stream s);
+
+/* ---- single-operator entry points (parity tests of the individual kernels) ------------ */
+/* y = act(x @ W + b): x [M,K] (dtype dt), W [K,N] f32, y [M,N] (dt); scratch >= ishara_op_scratch_bytes */
+int64_t ishara_op_scratch_bytes(int32_t M, int32_t K, int32_t N);
+int ishara_op_dense_fwd(int32_t dt, const void* x, const float* W, const float* bias, void* y,
+                        int32_t M, int32_t K, int32_t N, int32_t act, void* scratch, ishara_stream s);
+/* dx = dy @ W^T ; dW += x^T dy ; db += colsum(dy) */
+int ishara_op_dense_bwd(int32_t dt, const void* x, const float* W, const void* dy, void* dx,
+                        float* dW, float* db, int32_t M, int32_t K, int32_t N, void* scratch, ishara_stream s);
+int ishara_op_layernorm_fwd(int32_t dt, const void* x, const float* gamma, const float* beta, float eps,
+                            void* y, float* mean, float* rstd, int32_t M, int32_t C, ishara_stream s);
+int ishara_op_layernorm_bwd(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd,
+                            const float* gamma, void* dx, float* dgamma, float* dbeta, int32_t M, int32_t C,
+                            ishara_stream s);
+/* inop: 0 none, 1 swish, 2 GLU (x has 2C channels) */
+int ishara_op_dwconv_fwd(int32_t dt, int32_t inop, const void* x, const float* w, const float* bias, void* y,
+                         float* ssum, float* ssq, int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl,
+                         ishara_stream s);
+int ishara_op_dwconv_bwd(int32_t dt, int32_t inop, const void* dy, const void* x, const float* w, void* dx,
+                         float* dw, float* dbias, int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl,
+                         ishara_stream s);
+/* attention on packed qkv [B*T, 3*H*dh] (head-major packing): o [B*T, H*dh]; scratch holds q,k,vt,lse,delta */
+int64_t ishara_op_attn_scratch_bytes(int32_t B, int32_t H, int32_t T, int32_t dh);
+int ishara_op_attn_fwd(int32_t dt, const void* qkv, void* o, int32_t B, int32_t H, int32_t T, int32_t dh,
+                       float scale, uint32_t seed, uint32_t site, float rate, int32_t impl,
+                       void* scratch, ishara_stream s);
+int ishara_op_attn_bwd(int32_t dt, const void* o, const void* dout, void* dqkv, int32_t B, int32_t H,
+                       int32_t T, int32_t dh, float scale, uint32_t seed, uint32_t site, float rate,
+                       int32_t impl, void* scratch, ishara_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,131 @@
+// Shared device/host helpers for the ishara_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WAVE 64
+#define DEVI __device__ __forceinline__
+
+template <typename T> struct is_bf16_t { static constexpr bool value = false; };
+template <> struct is_bf16_t<bf16> { static constexpr bool value = true; };
+
+DEVI float to_f(float v) { return v; }
+DEVI float to_f(bf16 v) { return (float)v; }
+template <typename T> DEVI T from_f(float v);
+template <> DEVI float from_f<float>(float v) { return v; }
+template <> DEVI bf16 from_f<bf16>(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+
+// ---- 8-element vector IO (16 B for bf16, 2x16 B for f32) -------------------
+DEVI void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+DEVI void load8(const bf16* p, float (&v)[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+DEVI void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+DEVI void store8(bf16* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+// bounds-aware: n = number of valid elements (<=8); requires p 16-B aligned when n==8
+template <typename T> DEVI void load8_n(const T* p, float (&v)[8], int n) {
+    if (n >= 8) { load8(p, v); return; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (i < n) ? to_f(p[i]) : 0.f;
+}
+template <typename T> DEVI void store8_n(T* p, const float (&v)[8], int n) {
+    if (n >= 8) { store8(p, v); return; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i < n) p[i] = from_f<T>(v[i]);
+}
+DEVI void load4(const float* p, float (&v)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+
+DEVI void load4g(const float* p, float (&v)[4]) { load4(p, v); }
+DEVI void load4g(const bf16* p, float (&v)[4]) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+}
+DEVI void store4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+DEVI void store4(bf16* p, const float (&v)[4]) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x4*>(p) = a;
+}
+
+// ---- math ---------------------------------------------------------------------
+DEVI float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+DEVI float swishf_(float x) { return x * sigmoidf_(x); }
+DEVI float dswishf_(float x) { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+
+// ---- wave / block reductions ----------------------------------------------------
+DEVI float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVI float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- counter-based dropout RNG (mirrored by oracle/rng.py) ----------------------
+__host__ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t rng_site_key(uint32_t seed, uint32_t site) {
+    return lowbias32(seed ^ (site * 0x9E3779B9u));
+}
+__host__ __device__ __forceinline__ uint32_t rng_row_key(uint32_t site_key, uint32_t row) {
+    return lowbias32(site_key ^ (row * 0x85EBCA6Bu));
+}
+__host__ __device__ __forceinline__ bool rng_keep(uint32_t row_key, uint32_t col, uint32_t thr) {
+    return lowbias32(row_key ^ col) >= thr;
+}
+static inline uint32_t rng_threshold(float rate) {
+    double t = (double)rate * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+struct DropSpec {          // one dropout application
+    uint32_t key;          // rng_site_key(seed, site)
+    uint32_t thr;          // keep iff hash >= thr ; thr==0 -> disabled
+    float scale;           // 1/(1-rate)
+};
+static inline DropSpec make_drop(uint32_t seed, uint32_t site, float rate, bool training) {
+    DropSpec d;
+    d.key = rng_site_key(seed, site);
+    d.thr = (training && rate > 0.f) ? rng_threshold(rate) : 0u;
+    d.scale = (training && rate > 0.f) ? 1.0f / (1.0f - rate) : 1.0f;
+    return d;
+}
+
+#define HIP_CHECK_RET(expr)                                                         \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) { ishara_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); return -2; } \
+    } while (0)
+
+void ishara_set_error(const char* fmt, ...);

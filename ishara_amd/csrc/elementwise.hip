@@ -1,0 +1,784 @@
+// HBM-bound kernels of the Ishara encoder: LayerNorm, depthwise conv (causal / same,
+// fused Swish / GLU input ops, fused BatchNorm + GAP statistics), BatchNorm / ECA /
+// Squeeze-Excite small ops and their backward passes.  Activations are [B*T, C]
+// row-major (channel fastest), read and written as 16-byte (8 x bf16) or 2 x 16-byte
+// (8 x f32) chunks per lane; all arithmetic is fp32.
+#include "kernels.h"
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
+
+static inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// =====================================================================================
+// LayerNorm.  A row is owned by a group of G lanes (G = pow2 >= C/8, <= 64), each lane
+// holding one 8-channel chunk in registers (C <= 512) -> exact two-pass statistics.
+// =====================================================================================
+template <int G> DEVI float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int C) {
+    constexpr int RPB = 256 / G;
+    const int tid = threadIdx.x, gl = tid % G, gr = tid / G;
+    const int nch = C >> 3;
+    const bool act = gl < nch;
+    float ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ga[e] = act ? gamma[gl * 8 + e] : 0.f; be[e] = act ? beta[gl * 8 + e] : 0.f; }
+    for (int row = blockIdx.x * RPB + gr; row < M; row += gridDim.x * RPB) {
+        float v[8];
+        if (act) load8(x + (size_t)row * C + gl * 8, v);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        const float mu = group_sum<G>(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = act ? v[e] - mu : 0.f; q += d * d; }
+        const float rs = rsqrtf(group_sum<G>(q) / (float)C + eps);
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu) * rs * ga[e] + be[e];
+            store8(y + (size_t)row * C + gl * 8, v);
+        }
+        if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float* beta, float eps,
+                         void* y, float* mean, float* rstd, int M, int C, hipStream_t s) {
+    if (C % 8 != 0 || C > 512) { ishara_set_error("layernorm: C=%d unsupported (need C%%8==0, C<=512)", C); return -1; }
+    const int G = next_pow2(C / 8);
+    const int rpb = 256 / G;
+    const int grid = min((M + rpb - 1) / rpb, 4096);
+#define LN_F(TT, GG) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, GG>), dim3(grid), dim3(256), 0, s, (const TT*)x, gamma, beta, eps, (TT*)y, mean, rstd, M, C)
+#define LN_FG(TT) switch (G) { case 1: LN_F(TT, 1); break; case 2: LN_F(TT, 2); break; case 4: LN_F(TT, 4); break; case 8: LN_F(TT, 8); break; \
+                               case 16: LN_F(TT, 16); break; case 32: LN_F(TT, 32); break; default: LN_F(TT, 64); break; }
+    if (dt == DT_BF16) { LN_FG(bf16) } else { LN_FG(float) }
+    return LAUNCH_OK();
+}
+
+// dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat)) (+ resid); dgamma += sum_rows dy*xhat; dbeta += sum_rows dy
+template <typename T, int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const T* __restrict__ resid,
+                                                            T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int M, int C) {
+    constexpr int RPB = 256 / G;
+    __shared__ float red[2][256][8];
+    const int tid = threadIdx.x, gl = tid % G, gr = tid / G;
+    const int nch = C >> 3;
+    const bool act = gl < nch;
+    float ga[8], dg[8], db[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ga[e] = act ? gamma[gl * 8 + e] : 0.f; dg[e] = 0.f; db[e] = 0.f; }
+    for (int row = blockIdx.x * RPB + gr; row < M; row += gridDim.x * RPB) {
+        float d[8], xv[8];
+        if (act) { load8(dy + (size_t)row * C + gl * 8, d); load8(x + (size_t)row * C + gl * 8, xv); }
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { d[e] = 0.f; xv[e] = 0.f; }
+        }
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xv[e] = act ? (xv[e] - mu) * rs : 0.f;     // xhat
+            dg[e] += d[e] * xv[e];
+            db[e] += d[e];
+            d[e] *= ga[e];
+            s1 += d[e];
+            s2 += d[e] * xv[e];
+        }
+        s1 = group_sum<G>(s1) / (float)C;
+        s2 = group_sum<G>(s2) / (float)C;
+        if (act) {
+            float o[8];
+            if (resid) load8(resid + (size_t)row * C + gl * 8, o);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += rs * (d[e] - s1 - xv[e] * s2);
+            store8(dx + (size_t)row * C + gl * 8, o);
+        }
+    }
+    // reduce dgamma/dbeta over the RPB row groups of the block, then one atomic per channel
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][tid][e] = dg[e]; red[1][tid][e] = db[e]; }
+    __syncthreads();
+    if (gr == 0 && act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < RPB; ++r) { a += red[0][r * G + gl][e]; b += red[1][r * G + gl][e]; }
+            atomicAdd(dgamma + gl * 8 + e, a);
+            atomicAdd(dbeta + gl * 8 + e, b);
+        }
+    }
+}
+
+int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd,
+                         const float* gamma, const void* resid, void* dx, float* dgamma, float* dbeta,
+                         int M, int C, hipStream_t s) {
+    if (C % 8 != 0 || C > 512) { ishara_set_error("layernorm_bwd: C=%d unsupported", C); return -1; }
+    const int G = next_pow2(C / 8);
+    const int rpb = 256 / G;
+    const int grid = min((M + rpb - 1) / rpb, 1024);
+#define LN_B(TT, GG) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, GG>), dim3(grid), dim3(256), 0, s, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)resid, (TT*)dx, dgamma, dbeta, M, C)
+#define LN_BG(TT) switch (G) { case 1: LN_B(TT, 1); break; case 2: LN_B(TT, 2); break; case 4: LN_B(TT, 4); break; case 8: LN_B(TT, 8); break; \
+                               case 16: LN_B(TT, 16); break; case 32: LN_B(TT, 32); break; default: LN_B(TT, 64); break; }
+    if (dt == DT_BF16) { LN_BG(bf16) } else { LN_BG(float) }
+    return LAUNCH_OK();
+}
+
+// =====================================================================================
+// Depthwise conv over time.  One workgroup = 64 output steps x 128 channels of one sample.
+// The input tile (+ k-1 halo) is transformed once (Swish / GLU) and staged in LDS as fp32;
+// each thread slides an 8-step register window over its 4 channels.
+//   OUT_NONE  : y = conv (+bias), optional per-sample sum / sum-of-squares (BN stats, GAP)
+//   OUT_DSWISH: y = conv * swish'(aux)                 (backward through a Swish input op)
+//   OUT_DGLU  : y[:, :C] = conv*sig(a2) ; y[:, C:] = conv*a1*sig(a2)*(1-sig(a2))   (aux has 2C)
+// `flip` indexes the taps in reverse (backward data pass).
+// =====================================================================================
+enum : int { OUT_NONE = 0, OUT_DSWISH = 1, OUT_DGLU = 2 };
+#define DW_TT 64
+#define DW_CT 128
+#define DW_MAXK 31
+#define DWG_TT 32   // time tile of the weight-grad kernel (two LDS tiles must fit 64 KB)
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     T* __restrict__ y, const T* __restrict__ aux,
+                                                     float* __restrict__ ssum, float* __restrict__ ssq,
+                                                     int B, int Tn, int C, int k, int padl, int inop, int outop, int flip) {
+    __shared__ __attribute__((aligned(16))) float tile[(DW_TT + DW_MAXK - 1) * DW_CT];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
+    const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
+    const int rows = DW_TT + k - 1;
+    // ---- stage: thread -> chunk (tid&15) of 8 channels, rows (tid>>4) + 16*it
+    {
+        const int ch = c0 + (tid & 15) * 8;
+        for (int r = tid >> 4; r < rows; r += 16) {
+            const int tin = t0 - padl + r;
+            float v[8];
+            if (tin >= 0 && tin < Tn && ch < C) {
+                const T* p = x + ((size_t)b * Tn + tin) * Cin + ch;
+                load8(p, v);
+                if (inop == DWIN_SWISH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+                } else if (inop == DWIN_GLU) {
+                    float g[8];
+                    load8(p + C, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(g[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            float* dst = tile + r * DW_CT + (tid & 15) * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+    __syncthreads();
+    // ---- compute: thread -> 4 channels (cl) x 8 consecutive steps (tl)
+    const int cl = tid & 31, tl = tid >> 5;
+    const int ch = c0 + cl * 4;
+    const bool cact = ch < C;
+    float acc[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][e] = 0.f;
+    if (cact) {
+        float4 win[8];
+        const float* tp = tile + (tl * 8) * DW_CT + cl * 4;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) win[r + 1] = *reinterpret_cast<const float4*>(tp + r * DW_CT);
+        // invariant at tap j: win[1..7] = tile rows tl*8 + j + (0..6); each tap shifts and loads one row
+        for (int j = 0; j < k; ++j) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) win[r] = win[r + 1];
+            win[7] = *reinterpret_cast<const float4*>(tp + (j + 7) * DW_CT);
+            const float4 wj = *reinterpret_cast<const float4*>(w + (size_t)(flip ? (k - 1 - j) : j) * C + ch);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc[r][0] += wj.x * win[r].x; acc[r][1] += wj.y * win[r].y;
+                acc[r][2] += wj.z * win[r].z; acc[r][3] += wj.w * win[r].w;
+            }
+        }
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cact) {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = bias[ch + e];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int t = t0 + tl * 8 + r;
+            if (t < Tn) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = acc[r][e] + bv[e]; s1[e] += o[e]; s2[e] += o[e] * o[e]; }
+                const size_t row = (size_t)b * Tn + t;
+                if (outop == OUT_NONE) {
+                    store4(y + row * C + ch, o);
+                } else if (outop == OUT_DSWISH) {
+                    float a[4];
+                    load4g(aux + row * C + ch, a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= dswishf_(a[e]);
+                    store4(y + row * C + ch, o);
+                } else {
+                    float a1[4], a2[4], o2[4];
+                    load4g(aux + row * 2 * C + ch, a1);
+                    load4g(aux + row * 2 * C + C + ch, a2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sg = sigmoidf_(a2[e]);
+                        o2[e] = o[e] * a1[e] * sg * (1.f - sg);
+                        o[e] *= sg;
+                    }
+                    store4(y + row * 2 * C + ch, o);
+                    store4(y + row * 2 * C + C + ch, o2);
+                }
+            }
+        }
+    }
+    if (ssum) {   // per-sample channel sums of this tile -> [B,C] (uniform branch)
+        __syncthreads();
+        float* red = tile;   // [8 tl][128 ch][2]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(tl * DW_CT + cl * 4 + e) * 2] = s1[e]; red[(tl * DW_CT + cl * 4 + e) * 2 + 1] = s2[e]; }
+        __syncthreads();
+        if (tid < DW_CT && c0 + tid < C) {
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { a += red[(r * DW_CT + tid) * 2]; q += red[(r * DW_CT + tid) * 2 + 1]; }
+            atomicAdd(ssum + (size_t)b * C + c0 + tid, a);
+            if (ssq) atomicAdd(ssq + (size_t)b * C + c0 + tid, q);
+        }
+    }
+}
+
+static int dwconv_check(int C, int k) {
+    if (C % 8 != 0) { ishara_set_error("dwconv: C=%d must be a multiple of 8", C); return -1; }
+    if (k < 1 || k > DW_MAXK) { ishara_set_error("dwconv: kernel size %d unsupported (1..%d)", k, DW_MAXK); return -1; }
+    return 0;
+}
+
+int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const float* bias, void* y,
+                      float* colsum, float* colsq, int B, int T, int C, int k, int padl, hipStream_t s) {
+    if (dwconv_check(C, k)) return -1;
+    dim3 grid((T + DW_TT - 1) / DW_TT, (C + DW_CT - 1) / DW_CT, B);
+    if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0);
+    else hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0);
+    return LAUNCH_OK();
+}
+
+// dw[j,c] += sum_{b,t} dy[b,t,c] * in(x)[b, t-padl+j, c] ; dbias[c] += sum dy.
+// grid = (C/128, splits); each workgroup loops over (sample, time-tile) pairs and issues
+// one atomic per (tap, channel) at the end.  thread -> 4 channels x taps {tl, tl+8, tl+16, tl+24}.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                           int B, int Tn, int C, int k, int padl, int inop) {
+    __shared__ __attribute__((aligned(16))) float xt[(DWG_TT + DW_MAXK - 1) * DW_CT];
+    __shared__ __attribute__((aligned(16))) float dt_[DWG_TT * DW_CT];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * DW_CT;
+    const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
+    const int rows = DWG_TT + k - 1;
+    const int ntt = (Tn + DWG_TT - 1) / DWG_TT;
+    const int cl = tid & 31, tl = tid >> 5;
+    float acc[4][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q][e] = 0.f;
+    for (int item = blockIdx.y; item < B * ntt; item += gridDim.y) {
+        const int b = item / ntt, t0 = (item % ntt) * DWG_TT;
+        const int ch8 = c0 + (tid & 15) * 8;
+        for (int r = tid >> 4; r < rows; r += 16) {
+            const int tin = t0 - padl + r;
+            float v[8];
+            if (tin >= 0 && tin < Tn && ch8 < C) {
+                const T* p = x + ((size_t)b * Tn + tin) * Cin + ch8;
+                load8(p, v);
+                if (inop == DWIN_SWISH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+                } else if (inop == DWIN_GLU) {
+                    float g[8];
+                    load8(p + C, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(g[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            float* dst = xt + r * DW_CT + (tid & 15) * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        for (int r = tid >> 4; r < DWG_TT; r += 16) {
+            const int t = t0 + r;
+            float v[8];
+            if (t < Tn && ch8 < C) load8(dy + ((size_t)b * Tn + t) * C + ch8, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            float* dst = dt_ + r * DW_CT + (tid & 15) * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        __syncthreads();
+        for (int t = 0; t < DWG_TT; ++t) {
+            const float4 d = *reinterpret_cast<const float4*>(dt_ + t * DW_CT + cl * 4);
+            if (tl == 0) { accb[0] += d.x; accb[1] += d.y; accb[2] += d.z; accb[3] += d.w; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = tl + 8 * q;
+                if (j < k) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xt + (t + j) * DW_CT + cl * 4);
+                    acc[q][0] += d.x * xv.x; acc[q][1] += d.y * xv.y; acc[q][2] += d.z * xv.z; acc[q][3] += d.w * xv.w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int ch = c0 + cl * 4;
+    if (ch < C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = tl + 8 * q;
+            if (j < k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dw + (size_t)j * C + ch + e, acc[q][e]);
+            }
+        }
+        if (dbias && tl == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dbias + ch + e, accb[e]);
+        }
+    }
+}
+
+int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const float* w, void* dx,
+                      float* dw, float* dbias, int B, int T, int C, int k, int padl, hipStream_t s) {
+    if (dwconv_check(C, k)) return -1;
+    // data grad: correlation with flipped taps, left pad k-1-padl; then through the input op
+    {
+        dim3 grid((T + DW_TT - 1) / DW_TT, (C + DW_CT - 1) / DW_CT, B);
+        const int outop = inop == DWIN_SWISH ? OUT_DSWISH : (inop == DWIN_GLU ? OUT_DGLU : OUT_NONE);
+        if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, w, (const float*)nullptr, (bf16*)dx, (const bf16*)x, (float*)nullptr, (float*)nullptr, B, T, C, k, k - 1 - padl, (int)DWIN_NONE, outop, 1);
+        else hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, w, (const float*)nullptr, (float*)dx, (const float*)x, (float*)nullptr, (float*)nullptr, B, T, C, k, k - 1 - padl, (int)DWIN_NONE, outop, 1);
+    }
+    {
+        const int ntt = (T + DWG_TT - 1) / DWG_TT;
+        const int cblocks = (C + DW_CT - 1) / DW_CT;
+        int splits = max(1, min(B * ntt, 1024 / cblocks));
+        dim3 grid(cblocks, splits);
+        if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, dw, dbias, B, T, C, k, padl, inop);
+        else hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, dw, dbias, B, T, C, k, padl, inop);
+    }
+    return LAUNCH_OK();
+}
+
+// =====================================================================================
+// per-sample reductions over time:  S1[b,c] += sum_t dy ; S2[b,c] += sum_t dy * o,
+// o = other (optionally normalised (other-mean)*rstd).  grid = (B, time splits).
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void sample_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ other,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ S1, float* __restrict__ S2, int B, int Tn, int C) {
+    __shared__ float red[2][256][8];
+    const int tid = threadIdx.x;
+    const int nch = C >> 3;
+    const int CL = min(nch, 256), RL = 256 / CL;
+    const int cl = tid % CL, rl = tid / CL;
+    const int b = blockIdx.x;
+    const int tper = (Tn + gridDim.y - 1) / gridDim.y;
+    const int tb = blockIdx.y * tper, te = min(Tn, tb + tper);
+    for (int cb = 0; cb < nch; cb += CL) {
+        const int chunk = cb + cl;
+        const bool act = chunk < nch && rl < RL;
+        float a[8], q[8], mu[8], rs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; mu[e] = (act && mean) ? mean[chunk * 8 + e] : 0.f; rs[e] = (act && mean) ? rstd[chunk * 8 + e] : 1.f; }
+        if (act) {
+            for (int t = tb + rl; t < te; t += RL) {
+                float d[8], o[8];
+                const size_t off = ((size_t)b * Tn + t) * C + chunk * 8;
+                load8(dy + off, d);
+                if (other) load8(other + off, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a[e] += d[e]; if (other) q[e] += d[e] * ((o[e] - mu[e]) * rs[e]); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][tid][e] = a[e]; red[1][tid][e] = q[e]; }
+        __syncthreads();
+        if (rl == 0 && chunk < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sa = 0.f, sq = 0.f;
+                for (int r = 0; r < RL; ++r) { sa += red[0][r * CL + cl][e]; sq += red[1][r * CL + cl][e]; }
+                atomicAdd(S1 + (size_t)b * C + chunk * 8 + e, sa);
+                if (S2) atomicAdd(S2 + (size_t)b * C + chunk * 8 + e, sq);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_sample_reduce(int dt, const void* dy, const void* other, const float* mean, const float* rstd,
+                         float* S1, float* S2, int B, int T, int C, hipStream_t s) {
+    if (C % 8 != 0) { ishara_set_error("sample_reduce: C%%8 != 0"); return -1; }
+    (void)hipMemsetAsync(S1, 0, (size_t)B * C * sizeof(float), s);
+    if (S2) (void)hipMemsetAsync(S2, 0, (size_t)B * C * sizeof(float), s);
+    int ts = max(1, min(8, 1024 / max(B, 1)));
+    ts = min(ts, max(1, T / 16));
+    dim3 grid(B, ts);
+    if (dt == DT_BF16) hipLaunchKernelGGL(sample_reduce_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)other, mean, rstd, S1, S2, B, T, C);
+    else hipLaunchKernelGGL(sample_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)other, mean, rstd, S1, S2, B, T, C);
+    return LAUNCH_OK();
+}
+
+// =====================================================================================
+// BatchNorm finalize from per-sample sums [nb, C] (fp64 accumulation across samples)
+// =====================================================================================
+__global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nb, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ mmean, float* __restrict__ mvar, int training,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ bsh, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu, var;
+    if (training) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nb; ++b) { s += (double)ssum[(size_t)b * C + c]; q += (double)ssq[(size_t)b * C + c]; }
+        const double m = s / (double)count;
+        double v = q / (double)count - m * m;
+        if (v < 0.0) v = 0.0;
+        mu = (float)m; var = (float)v;
+        mmean[c] = mmean[c] * momentum + mu * (1.f - momentum);
+        mvar[c] = mvar[c] * momentum + var * (1.f - momentum);
+    } else { mu = mmean[c]; var = mvar[c]; }
+    const float rs = rsqrtf(var + eps);
+    mean[c] = mu; rstd[c] = rs;
+    const float aa = gamma[c] * rs;
+    a[c] = aa; bsh[c] = beta[c] - mu * aa;
+}
+
+int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count, const float* gamma, const float* beta,
+                          float eps, float momentum, float* moving_mean, float* moving_var, int training,
+                          float* mean, float* rstd, float* a, float* b, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, ssum, ssq, nb, count, gamma, beta, eps, momentum,
+                       moving_mean, moving_var, training, mean, rstd, a, b, C);
+    return LAUNCH_OK();
+}
+
+// =====================================================================================
+// ECA gate on [B,C] (one workgroup per sample)
+// =====================================================================================
+__global__ __launch_bounds__(256) void eca_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ a, const float* __restrict__ bsh,
+                                                      const float* __restrict__ w5, float invT, float* __restrict__ gn,
+                                                      float* __restrict__ sg, float* __restrict__ P, float* __restrict__ Q, int C) {
+    extern __shared__ float sh[];   // [C + 4]
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C + 4; c += blockDim.x) {
+        const int cc = c - 2;
+        float g = 0.f;
+        if (cc >= 0 && cc < C) { g = a[cc] * gap[(size_t)b * C + cc] * invT + bsh[cc]; gn[(size_t)b * C + cc] = g; }
+        sh[c] = g;
+    }
+    __syncthreads();
+    const float w0 = w5[0], w1 = w5[1], w2 = w5[2], w3 = w5[3], w4 = w5[4];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float z = w0 * sh[c] + w1 * sh[c + 1] + w2 * sh[c + 2] + w3 * sh[c + 3] + w4 * sh[c + 4];
+        const float sv = sigmoidf_(z);
+        sg[(size_t)b * C + c] = sv;
+        P[(size_t)b * C + c] = a[c] * sv;
+        Q[(size_t)b * C + c] = bsh[c] * sv;
+    }
+}
+
+int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
+                   float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, gap, a, b, w5, invT, gn, sgate, P, Q, C);
+    return LAUNCH_OK();
+}
+
+// =====================================================================================
+// y = x*P[b,c] + Q[b,c] (+resid)  /  y = x*a[c] + b[c]
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ x, const float* __restrict__ P, const float* __restrict__ Q,
+                                                     const T* __restrict__ resid, T* __restrict__ y, size_t nchunks, int Tn, int C, int per_sample) {
+    const int nch = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / nch;
+        const int ch = (int)(i - row * nch) * 8;
+        const size_t pb = per_sample ? (row / Tn) * C + ch : ch;
+        float v[8];
+        load8(x + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * P[pb + e] + (Q ? Q[pb + e] : 0.f);
+        if (resid) {
+            float r[8];
+            load8(resid + i * 8, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        store8(y + i * 8, v);
+    }
+}
+
+static int run_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y, size_t rows, int T, int C, int per_sample, hipStream_t s) {
+    if (C % 8 != 0) { ishara_set_error("affine: C%%8 != 0"); return -1; }
+    const size_t nchunks = rows * (C / 8);
+    const int grid = (int)min((nchunks + 255) / 256, (size_t)8192);
+    if (dt == DT_BF16) hipLaunchKernelGGL(affine_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, P, Q, (const bf16*)resid, (bf16*)y, nchunks, T, C, per_sample);
+    else hipLaunchKernelGGL(affine_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, P, Q, (const float*)resid, (float*)y, nchunks, T, C, per_sample);
+    return LAUNCH_OK();
+}
+int launch_sample_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y, int B, int T, int C, hipStream_t s) {
+    return run_affine(dt, x, P, Q, resid, y, (size_t)B * T, T, C, 1, s);
+}
+int launch_col_affine(int dt, const void* x, const float* a, const float* b, void* y, int M, int C, hipStream_t s) {
+    return run_affine(dt, x, a, b, nullptr, y, (size_t)M, 1, C, 0, s);
+}
+
+// =====================================================================================
+// BatchNorm backward pieces
+// =====================================================================================
+// Conv1DBlock (BN -> ECA): step 1, per sample.  E <- dgn[b,c]; dw5 += sum dz*gn(shifted)
+__global__ __launch_bounds__(256) void eca_bwd_sample_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                                             const float* __restrict__ gn, const float* __restrict__ sg,
+                                                             const float* __restrict__ w5, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ E,
+                                                             float* __restrict__ dw5, int C) {
+    extern __shared__ float sh[];   // dz[C+4], g[C+4]
+    float* dz = sh;
+    float* g = sh + C + 4;
+    __shared__ float wred[5][4];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C + 4; c += blockDim.x) {
+        const int cc = c - 2;
+        float z = 0.f, gg = 0.f;
+        if (cc >= 0 && cc < C) {
+            const size_t i = (size_t)b * C + cc;
+            const float ds = gamma[cc] * S2[i] + beta[cc] * S1[i];
+            const float sv = sg[i];
+            z = ds * sv * (1.f - sv);
+            gg = gn[i];
+        }
+        dz[c] = z; g[c] = gg;
+    }
+    __syncthreads();
+    float wp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        // dgn[c] = sum_j w5[j] * dz[c - j + 2]  -> padded index (c - j + 2) + 2
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc += w5[j] * dz[c - j + 4];
+        E[(size_t)b * C + c] = acc;
+        // dw5[j] += dz[c] * gn[c + j - 2] -> padded g index c + j
+        const float z = dz[c + 2];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) wp[j] += z * g[c + j];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { const float v = wave_sum(wp[j]); if (lane == 0) wred[j][wid] = v; }
+    __syncthreads();
+    if (threadIdx.x < 5) atomicAdd(dw5 + threadIdx.x, wred[threadIdx.x][0] + wred[threadIdx.x][1] + wred[threadIdx.x][2] + wred[threadIdx.x][3]);
+}
+
+// step 2, per channel: dgamma, dbeta, Fc; E[b,c] <- dgn/T - dbeta/Mtot
+__global__ void eca_bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ gap,
+                                          const float* __restrict__ sg, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ E, float* __restrict__ Fc,
+                                          int B, int Tn, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invT = 1.f / (float)Tn, mu = mean[c], rs = rstd[c];
+    double dg = 0.0, db = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const size_t i = (size_t)b * C + c;
+        const float ghat = (gap[i] * invT - mu) * rs;
+        dg += (double)(sg[i] * S2[i] + E[i] * ghat);
+        db += (double)(sg[i] * S1[i] + E[i]);
+    }
+    const float mtot = (float)B * (float)Tn;
+    dgamma[c] += (float)dg;
+    dbeta[c] += (float)db;
+    Fc[c] = (float)dg / mtot;
+    const float eb = (float)db / mtot;
+    for (int b = 0; b < B; ++b) { const size_t i = (size_t)b * C + c; E[i] = E[i] * invT - eb; }
+}
+
+int launch_eca_bn_bwd_finalize(const float* S1, const float* S2, const float* gap, const float* gn, const float* sgate,
+                               const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, int B, int T, int C, hipStream_t s) {
+    hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B), dim3(256), 2 * (C + 4) * sizeof(float), s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5, C);
+    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + 63) / 64), dim3(64), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, B, T, C);
+    return LAUNCH_OK();
+}
+
+__global__ void bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, float* __restrict__ Ecol, float* __restrict__ Fc, int B, int Tn, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (int b = 0; b < B; ++b) { dg += (double)S2[(size_t)b * C + c]; db += (double)S1[(size_t)b * C + c]; }
+    const float mtot = (float)B * (float)Tn;
+    dgamma[c] += (float)dg;
+    dbeta[c] += (float)db;
+    Fc[c] = (float)dg / mtot;
+    Ecol[c] = -(float)db / mtot;
+}
+
+int launch_bn_bwd_finalize(const float* S1, const float* S2, float* dgamma, float* dbeta, float* Ecol, float* Fc,
+                           int B, int T, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_channel_kernel, dim3((C + 63) / 64), dim3(64), 0, s, S1, S2, dgamma, dbeta, Ecol, Fc, B, T, C);
+    return LAUNCH_OK();
+}
+
+// dx = a[c] * (dy*sg[b,c] + E - xhat*Fc[c])
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ a, const float* __restrict__ sg,
+                                                           const float* __restrict__ E, int e_per_sample, const float* __restrict__ Fc,
+                                                           T* __restrict__ dx, size_t nchunks, int Tn, int C) {
+    const int nch = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / nch;
+        const int ch = (int)(i - row * nch) * 8;
+        const size_t sb = (row / Tn) * C + ch;
+        float d[8], xv[8];
+        load8(dy + i * 8, d);
+        load8(x + i * 8, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = (xv[e] - mean[ch + e]) * rstd[ch + e];
+            const float g = sg ? sg[sb + e] : 1.f;
+            const float ee = e_per_sample ? E[sb + e] : E[ch + e];
+            d[e] = a[ch + e] * (d[e] * g + ee - xh * Fc[ch + e]);
+        }
+        store8(dx + i * 8, d);
+    }
+}
+
+int launch_bn_bwd_apply(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* a,
+                        const float* sg, const float* E, int e_per_sample, const float* Fc, void* dx,
+                        int B, int T, int C, hipStream_t s) {
+    if (C % 8 != 0) { ishara_set_error("bn_bwd_apply: C%%8 != 0"); return -1; }
+    const size_t nchunks = (size_t)B * T * (C / 8);
+    const int grid = (int)min((nchunks + 255) / 256, (size_t)8192);
+    if (dt == DT_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, mean, rstd, a, sg, E, e_per_sample, Fc, (bf16*)dx, nchunks, T, C);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, mean, rstd, a, sg, E, e_per_sample, Fc, (float*)dx, nchunks, T, C);
+    return LAUNCH_OK();
+}
+
+// =====================================================================================
+// Squeeze-Excite MLP (one workgroup per sample; C <= 1024, R <= 128)
+// =====================================================================================
+__global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ gap, float invT, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                     const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ hid_pre,
+                                                     float* __restrict__ se, int C, int R) {
+    extern __shared__ float sh[];   // z[C], h[R]
+    float* z = sh;
+    float* h = sh + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) z[c] = gap[(size_t)b * C + c] * invT;
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        float acc = b1[r];
+        for (int c = 0; c < C; ++c) acc += z[c] * W1[(size_t)c * R + r];
+        hid_pre[(size_t)b * R + r] = acc;
+        h[r] = swishf_(acc);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = b2[c];
+        for (int r = 0; r < R; ++r) acc += h[r] * W2[(size_t)r * C + c];
+        se[(size_t)b * C + c] = sigmoidf_(acc);
+    }
+}
+
+int launch_se_fwd(const float* gap, float invT, const float* W1, const float* b1, const float* W2, const float* b2,
+                  float* hid_pre, float* se, int B, int C, int R, hipStream_t s) {
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, gap, invT, W1, b1, W2, b2, hid_pre, se, C, R);
+    return LAUNCH_OK();
+}
+
+__global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ dse, const float* __restrict__ gap, float invT,
+                                                     const float* __restrict__ W1, const float* __restrict__ W2,
+                                                     const float* __restrict__ hid_pre, const float* __restrict__ se,
+                                                     float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                                     float* __restrict__ dgapT, int C, int R) {
+    extern __shared__ float sh[];   // z[C], dp2[C], h[R], dhp[R]
+    float* z = sh;
+    float* dp2 = sh + C;
+    float* h = sh + 2 * C;
+    float* dhp = sh + 2 * C + R;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const size_t i = (size_t)b * C + c;
+        z[c] = gap[i] * invT;
+        const float sv = se[i];
+        const float d = dse[i] * sv * (1.f - sv);
+        dp2[c] = d;
+        atomicAdd(db2 + c, d);
+    }
+    for (int r = threadIdx.x; r < R; r += blockDim.x) h[r] = swishf_(hid_pre[(size_t)b * R + r]);
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += W2[(size_t)r * C + c] * dp2[c];
+        const float d = acc * dswishf_(hid_pre[(size_t)b * R + r]);
+        dhp[r] = d;
+        atomicAdd(db1 + r, d);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * R; i += blockDim.x) {
+        const int r2 = i / C, c2 = i - r2 * C;          // dW2[r][c] = h[r]*dp2[c]
+        atomicAdd(dW2 + i, h[r2] * dp2[c2]);
+        const int c1 = i / R, r1 = i - c1 * R;          // dW1[c][r] = z[c]*dhp[r]
+        atomicAdd(dW1 + i, z[c1] * dhp[r1]);
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += W1[(size_t)c * R + r] * dhp[r];
+        dgapT[(size_t)b * C + c] = acc * invT;
+    }
+}
+
+int launch_se_bwd(const float* dse, const float* gap, float invT, const float* W1, const float* W2,
+                  const float* hid_pre, const float* se, float* dW1, float* db1, float* dW2, float* db2,
+                  float* dgapT, int B, int C, int R, hipStream_t s) {
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (2 * C + 2 * R) * sizeof(float), s, dse, gap, invT, W1, W2, hid_pre, se, dW1, db1, dW2, db2, dgapT, C, R);
+    return LAUNCH_OK();
+}

@@ -1,0 +1,619 @@
+// MFMA GEMMs for the dense projections of the Ishara encoder (gfx950 / CDNA4).
+//
+//   gemm_nt : C[M,N]  = epi( op(A)[M,K] . Bt[N,K]^T )       forward + dgrad
+//   gemm_tn : dW[K,N] += opA(A)[M,K]^T . opB(B)[M,N]         wgrad (+ bias grad), split over M
+//
+// M = batch*frames is huge (98,304 for B256,T384) while N,K <= 768, so both kernels
+// stream the activation operand once from HBM and keep the weight tile L2-resident.
+// One 256-thread workgroup (4 waves, 2x2) owns a 128x128 output tile; each wave a 64x64
+// sub-tile = 4x4 MFMA 16x16 accumulators.  bf16 mode uses v_mfma_f32_16x16x32_bf16,
+// f32 mode uses the exact-f32 v_mfma_f32_16x16x4_f32 (same tile structure, K tile is
+// 128 bytes per row in both: 64 bf16 / 32 f32).  Operands are register-staged
+// (global -> VGPR -> transform -> LDS, issue-early/write-late) into a double-buffered,
+// XOR-swizzled LDS image; the accumulators leave through an fp32 LDS stage so that
+// the fused epilogue (bias, PE table, activation, dropout, drop-path, act', residual,
+// QKV head split with V transposed) runs on whole 8-element row chunks with 16-byte
+// coalesced global accesses.
+#include "kernels.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <typename TM> struct MmaCfg;
+template <> struct MmaCfg<bf16>  { static constexpr int EPC = 8; static constexpr int BK = 64; };
+template <> struct MmaCfg<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };
+
+// ---------------------------------------------------------------------------------
+// operand transforms
+// ---------------------------------------------------------------------------------
+template <int N>
+DEVI void apply_op(int op, float (&v)[N], int row, int col, const OpArgs& a) {
+    switch (op) {
+        case OP_SWISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = swishf_(v[e]);
+            break;
+        case OP_COLAFFINE:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] * a.c1[col + e] + a.c0[col + e];
+            break;
+        case OP_ROWSCALE: {
+            const float s = a.rs[row / a.T];
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] *= s;
+        } break;
+        case OP_DROPMASK:
+            if (a.drop.thr) {
+                const uint32_t rk = rng_row_key(a.drop.key, (uint32_t)row);
+#pragma unroll
+                for (int e = 0; e < N; ++e) v[e] = rng_keep(rk, (uint32_t)(col + e), a.drop.thr) ? v[e] * a.drop.scale : 0.f;
+            }
+            break;
+        default: break;
+    }
+}
+
+// load N (4 or 8) consecutive elements of row `row` starting at column `col`, zero filled
+// outside [rows x cols]; vec_ok = row stride and base are 16-byte aligned.
+template <typename T, int N>
+__device__ __attribute__((noinline)) void load_row_chunk_slow(const T* __restrict__ p, int nvalid, float (&v)[N]) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = (e < nvalid) ? to_f(p[e]) : 0.f;
+}
+template <typename T, int N>
+DEVI void load_row_chunk(const T* __restrict__ base, int ld, int rows, int cols, int row, int col,
+                         bool vec_ok, float (&v)[N]) {
+    if (row < rows && col < cols) {
+        const T* p = base + (size_t)row * ld + col;
+        if (vec_ok && col + N <= cols) {
+            if constexpr (N == 8) load8(p, v);
+            else {
+                if constexpr (is_bf16_t<T>::value) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(p);
+                    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+                    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+                } else load4(p, v);
+            }
+        } else {
+            load_row_chunk_slow<T, N>(p, cols - col, v);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = 0.f;
+    }
+}
+
+DEVI uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 t; t[0] = (bf16)lo; t[1] = (bf16)hi;
+    return __builtin_bit_cast(uint32_t, t);
+}
+template <typename TM, int N> DEVI u32x4 pack_chunk(const float (&v)[N]) {
+    u32x4 r;
+    if constexpr (is_bf16_t<TM>::value) {
+        r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
+        r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
+    } else {
+        r.x = __float_as_uint(v[0]); r.y = __float_as_uint(v[1]);
+        r.z = __float_as_uint(v[2]); r.w = __float_as_uint(v[3]);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------
+// MFMA over one LDS tile pair.  ldsA/ldsB: [128 rows][128 bytes], 16-byte slots XOR
+// swizzled by SWZ(row).  acc[i][j] = 16x16 tile (rows wr*64+16i.., cols wc*64+16j..).
+// ---------------------------------------------------------------------------------
+template <int SW> DEVI int swz(int row) { return SW == 0 ? (row & 7) : ((row ^ (row >> 3)) & 7); }
+
+template <typename TM, int SW>
+DEVI void mma_tile(const char* ldsA, const char* ldsB, int wr, int wc, int lane, f32x4 (&acc)[4][4]) {
+    const int r = lane & 15, g = lane >> 4;
+    if constexpr (is_bf16_t<TM>::value) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wr * 64 + 16 * i + r;
+                a[i] = *reinterpret_cast<const bf16x8*>(ldsA + row * 128 + (((4 * s + g) ^ swz<SW>(row)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wc * 64 + 16 * j + r;
+                b[j] = *reinterpret_cast<const bf16x8*>(ldsB + row * 128 + (((4 * s + g) ^ swz<SW>(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wr * 64 + 16 * i + r;
+                a[i] = *reinterpret_cast<const float*>(ldsA + row * 128 + ((s ^ swz<SW>(row)) << 4) + g * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wc * 64 + 16 * j + r;
+                b[j] = *reinterpret_cast<const float*>(ldsB + row * 128 + ((s ^ swz<SW>(row)) << 4) + g * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// epilogue on one 8-wide row chunk
+// ---------------------------------------------------------------------------------
+template <typename TC>
+DEVI void epilogue_chunk(float (&v)[8], int m, int n, int nv, int N, const EpiArgs& ea, TC* __restrict__ C) {
+    if (ea.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nv) v[e] += ea.bias[n + e];
+    }
+    if (ea.addtab) {
+        const float* t = ea.addtab + (size_t)(m % ea.tab_period) * N + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nv) v[e] += t[e];
+    }
+    const size_t off = (size_t)m * N + n;
+    if (ea.pre_out) store8_n(reinterpret_cast<TC*>(ea.pre_out) + off, v, nv);
+    if (ea.act == ACT_SWISH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+    } else if (ea.act == ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (ea.drop.thr) {
+        const uint32_t rk = rng_row_key(ea.drop.key, (uint32_t)m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rng_keep(rk, (uint32_t)(n + e), ea.drop.thr) ? v[e] * ea.drop.scale : 0.f;
+    }
+    if (ea.rowscale) {
+        const float s = ea.rowscale[m / ea.T];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= s;
+    }
+    if (ea.dact != DACT_NONE) {
+        float a[8];
+        load8_n(reinterpret_cast<const TC*>(ea.aux) + off, a, nv);
+        if (ea.dact == DACT_SWISH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dswishf_(a[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
+        }
+    }
+    if (ea.resid) {
+        float a[8];
+        load8_n(reinterpret_cast<const TC*>(ea.resid) + off, a, nv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += a[e];
+    }
+    if (ea.mode == EPI_STD) {
+        store8_n(C + off, v, nv);
+    } else {   // EPI_QKV: q,k parts only (v handled by the transposed sweep)
+        const int d = ea.H * ea.dh;
+        int h, part, i;
+        if (ea.head_major) { h = n / (3 * ea.dh); const int w = n - h * 3 * ea.dh; part = w / ea.dh; i = w - part * ea.dh; }
+        else { part = n / d; const int w = n - part * d; h = w / ea.dh; i = w - h * ea.dh; }
+        if (part < 2) {
+            const int b = m / ea.T, t = m - b * ea.T;
+            TC* dst = reinterpret_cast<TC*>(part == 0 ? ea.q : ea.k) + ((size_t)(b * ea.H + h) * ea.T + t) * ea.dh + i;
+            store8_n(dst, v, nv);
+        }
+    }
+}
+
+// stage one K tile of A (transformed) and Bt into registers: 4 x 16-byte chunks each per thread
+template <typename TA, typename TM, int OP>
+DEVI void nt_gload(const TA* __restrict__ A, const TM* __restrict__ Bt, int M, int K, int ldb, bool a_vec_ok,
+                   int m0, int n0, int kt, int tid, const OpArgs& oa, u32x4 (&ra)[4], u32x4 (&rb)[4]) {
+    constexpr int EPC = MmaCfg<TM>::EPC, BK = MmaCfg<TM>::BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
+        const int k = kt * BK + slot * EPC;
+        float v[EPC];
+        load_row_chunk<TA, EPC>(A, K, M, K, m0 + row, k, a_vec_ok, v);
+        if (OP != OP_NONE) {
+            apply_op<EPC>(OP, v, m0 + row, k, oa);
+            if (m0 + row >= M) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+            } else if (k + EPC > K) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) if (k + e >= K) v[e] = 0.f;
+            }
+        }
+        ra[i] = pack_chunk<TM, EPC>(v);
+        rb[i] = *reinterpret_cast<const u32x4*>(Bt + (size_t)(n0 + row) * ldb + k);
+    }
+}
+DEVI void nt_lstore(char* sa, int tid, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
+    char* sb = sa + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, slot = c & 7;
+        const int off = row * 128 + ((slot ^ (row & 7)) << 4);
+        *reinterpret_cast<u32x4*>(sa + off) = ra[i];
+        *reinterpret_cast<u32x4*>(sb + off) = rb[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// NT kernel
+// ---------------------------------------------------------------------------------
+template <typename TA, typename TM, typename TC, int OP>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const TA* __restrict__ A, const TM* __restrict__ Bt, TC* __restrict__ C,
+                                                      int M, int N, int K, int ldb, int a_vec_ok, OpArgs oa, EpiArgs ea) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];
+    constexpr int EPC = MmaCfg<TM>::EPC, BK = MmaCfg<TM>::BK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int nMt = (M + 127) >> 7, nNt = (N + 127) >> 7;
+    int mt, nt;
+    {   // XCD-aware mapping: blocks b, b+8 share an XCD (L2); keep one A row-panel's N tiles together
+        const int id = blockIdx.x;
+        if ((nMt & 7) == 0) { const int xcd = id & 7, local = id >> 3; mt = (local / nNt) * 8 + xcd; nt = local % nNt; }
+        else { mt = id / nNt; nt = id % nNt; }
+    }
+    const int m0 = mt << 7, n0 = nt << 7;
+    const int nk = (K + BK - 1) / BK;
+
+    u32x4 ra[4], rb[4];
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    nt_gload<TA, TM, OP>(A, Bt, M, K, ldb, a_vec_ok != 0, m0, n0, 0, tid, oa, ra, rb);
+    nt_lstore(smem, tid, ra, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) nt_gload<TA, TM, OP>(A, Bt, M, K, ldb, a_vec_ok != 0, m0, n0, kt + 1, tid, oa, ra, rb);
+        const char* sa = smem + (kt & 1) * 32768;
+        mma_tile<TM, 0>(sa, sa + 16384, wr, wc, lane, acc);
+        if (more) nt_lstore(smem + ((kt + 1) & 1) * 32768, tid, ra, rb);
+        __syncthreads();
+    }
+
+    // ---- epilogue through an fp32 LDS stage, 64 rows per pass ----
+    float* stage = reinterpret_cast<float*>(smem);   // [64][132]
+    constexpr int SLD = 132;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (wr == p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stage[(16 * i + 4 * (lane >> 4) + r) * SLD + wc * 64 + 16 * j + (lane & 15)] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int c = tid + 256 * qq, row = c >> 4, col = (c & 15) * 8;
+            const int m = m0 + 64 * p + row, n = n0 + col;
+            if (m < M && n < N) {
+                float v[8];
+                const float4 x0 = *reinterpret_cast<const float4*>(stage + row * SLD + col);
+                const float4 x1 = *reinterpret_cast<const float4*>(stage + row * SLD + col + 4);
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                epilogue_chunk<TC>(v, m, n, min(8, N - n), N, ea, C);
+            }
+        }
+        if (ea.mode == EPI_QKV) {   // V columns: write transposed vt[b,h,i,t], 8 consecutive t per store
+            const int d = ea.H * ea.dh;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int c = tid + 256 * qq, col = c & 127, rg = c >> 7;
+                const int n = n0 + col, mb = m0 + 64 * p + 8 * rg;
+                if (n < N && mb < M) {
+                    int h, part, i;
+                    if (ea.head_major) { h = n / (3 * ea.dh); const int w = n - h * 3 * ea.dh; part = w / ea.dh; i = w - part * ea.dh; }
+                    else { part = n / d; const int w = n - part * d; h = w / ea.dh; i = w - h * ea.dh; }
+                    if (part == 2) {
+                        float v[8];
+                        const float bias = ea.bias ? ea.bias[n] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = stage[(8 * rg + e) * SLD + col] + bias;
+                        const int b = mb / ea.T, t = mb - b * ea.T;
+                        TC* dst = reinterpret_cast<TC*>(ea.vt) + ((size_t)(b * ea.H + h) * ea.dh + i) * ea.T + t;
+                        store8_n(dst, v, min(8, M - mb));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TA, typename TM, typename TC, int OP>
+static int run_nt(const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s) {
+    const int nMt = (M + 127) / 128, nNt = (N + 127) / 128;
+    const int a_vec_ok = (((size_t)K * sizeof(TA)) % 16 == 0) && (((uintptr_t)A) % 16 == 0);
+    hipLaunchKernelGGL((gemm_nt_kernel<TA, TM, TC, OP>), dim3(nMt * nNt), dim3(256), 0, s,
+                       (const TA*)A, (const TM*)Bt, (TC*)C, M, N, K, ldb, a_vec_ok, oa, ea);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <typename TA, typename TM, typename TC>
+static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s) {
+    switch (op) {
+        case OP_NONE: return run_nt<TA, TM, TC, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+        case OP_SWISH: return run_nt<TA, TM, TC, OP_SWISH>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+        case OP_COLAFFINE: return run_nt<TA, TM, TC, OP_COLAFFINE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+        case OP_DROPMASK: return run_nt<TA, TM, TC, OP_DROPMASK>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+        default: ishara_set_error("gemm_nt: unsupported operand op %d", op); return -1;
+    }
+}
+
+int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
+                   int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) { ishara_set_error("gemm_nt: bad shape %d %d %d", M, N, K); return -1; }
+    if (ea.mode == EPI_QKV && (ea.T % 8 != 0 || N % 8 != 0 || ea.dh % 8 != 0)) {
+        ishara_set_error("gemm_nt: QKV split needs T, dh multiples of 8 (T=%d dh=%d)", ea.T, ea.dh); return -1;
+    }
+    if (dtA == DT_F32 && dtM == DT_F32 && dtC == DT_F32) return run_nt_op<float, float, float>(op, A, Bt, C, M, N, K, ldb, oa, ea, s);
+    if (dtA == DT_BF16 && dtM == DT_BF16 && dtC == DT_BF16) return run_nt_op<bf16, bf16, bf16>(op, A, Bt, C, M, N, K, ldb, oa, ea, s);
+    if (dtA == DT_F32 && dtM == DT_BF16 && dtC == DT_BF16 && op == OP_NONE) return run_nt<float, bf16, bf16, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+    if (dtA == DT_BF16 && dtM == DT_BF16 && dtC == DT_F32 && op == OP_NONE) return run_nt<bf16, bf16, float, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+    ishara_set_error("gemm_nt: unsupported dtype combination %d/%d/%d op %d", dtA, dtM, dtC, op);
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------
+// TN kernel (wgrad).  grid = (tiles_k * tiles_n, splits).  Both operands are staged
+// TRANSPOSED into LDS ([feature row][m contiguous]) so the MFMA fragment reads are the
+// same as in the NT kernel; swizzle SW=1 keeps both the 8-byte transposed writes and
+// the 16-byte fragment reads at <= 2-way bank conflicts.
+// ---------------------------------------------------------------------------------
+template <typename T, typename TM>
+DEVI void stage_t_load(const T* __restrict__ base, int ld, int m_end, int cols, int mbase, int col0, bool vec_ok,
+                       int op, const OpArgs& oa, int tid, u32x4 (&out)[4], float* colsum) {
+    // bf16 TM: thread -> kc = tid&15 (8 cols), mg = tid>>4 (4 rows of 64) ; out[e] holds rows for cols 2e,2e+1 (uint2 each)
+    // f32  TM: thread -> kc = tid&31 (4 cols), mg = tid>>5 (4 rows of 32) ; out[e] = 4 rows of col e
+    constexpr int EPC = MmaCfg<TM>::EPC;
+    const int kc = is_bf16_t<TM>::value ? (tid & 15) : (tid & 31);
+    const int mg = is_bf16_t<TM>::value ? (tid >> 4) : (tid >> 5);
+    float v[4][EPC];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = mbase + 4 * mg + r, col = col0 + kc * EPC;
+        load_row_chunk<T, EPC>(base, ld, m_end, cols, m, col, vec_ok, v[r]);
+        if (op != OP_NONE) {
+            apply_op<EPC>(op, v[r], m, col, oa);
+            if (m >= m_end) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[r][e] = 0.f;
+            } else if (col + EPC > cols) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) if (col + e >= cols) v[r][e] = 0.f;
+            }
+        }
+    }
+    if (colsum) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) colsum[e] += (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
+    }
+    if constexpr (is_bf16_t<TM>::value) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            out[e].x = pack_bf16x2(v[0][2 * e], v[1][2 * e]);         out[e].y = pack_bf16x2(v[2][2 * e], v[3][2 * e]);
+            out[e].z = pack_bf16x2(v[0][2 * e + 1], v[1][2 * e + 1]); out[e].w = pack_bf16x2(v[2][2 * e + 1], v[3][2 * e + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            out[e].x = __float_as_uint(v[0][e]); out[e].y = __float_as_uint(v[1][e]);
+            out[e].z = __float_as_uint(v[2][e]); out[e].w = __float_as_uint(v[3][e]);
+        }
+    }
+}
+
+template <typename TM>
+DEVI void stage_t_store(char* lds, int tid, const u32x4 (&r)[4]) {
+    if constexpr (is_bf16_t<TM>::value) {
+        const int kc = tid & 15, mg = tid >> 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 8 * kc + 2 * e + h;
+                const int off = row * 128 + (((mg >> 1) ^ swz<1>(row)) << 4) + ((mg & 1) << 3);
+                *reinterpret_cast<u32x2*>(lds + off) = h == 0 ? u32x2{r[e].x, r[e].y} : u32x2{r[e].z, r[e].w};
+            }
+        }
+    } else {
+        const int kc = tid & 31, mg = tid >> 5;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 4 * kc + e;
+            *reinterpret_cast<u32x4*>(lds + row * 128 + ((mg ^ swz<1>(row)) << 4)) = r[e];
+        }
+    }
+}
+
+template <typename TA, typename TB, typename TM>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TA* __restrict__ A, const TB* __restrict__ B,
+                                                      float* __restrict__ slab, float* __restrict__ bias_slab,
+                                                      int M, int Ka, int Nb, int rows_per_split, int a_vec_ok, int b_vec_ok,
+                                                      int opA, int opB, OpArgs oa, OpArgs ob) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];
+    constexpr int EPC = MmaCfg<TM>::EPC, MC = MmaCfg<TM>::BK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
+    const int nNt = (Nb + 127) >> 7;
+    const int kt = blockIdx.x / nNt, nt = blockIdx.x % nNt;
+    const int k0 = kt << 7, n0 = nt << 7;
+    const int split = blockIdx.y;
+    const int m_beg = split * rows_per_split;
+    const int m_end = min(M, m_beg + rows_per_split);
+    const int nmc = (m_end - m_beg + MC - 1) / MC;
+    const bool want_bias = (bias_slab != nullptr) && (kt == 0);
+
+    u32x4 ra[4], rb[4];
+    float csum[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) csum[e] = 0.f;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nmc > 0) {
+        stage_t_load<TA, TM>(A, Ka, m_end, Ka, m_beg, k0, a_vec_ok != 0, opA, oa, tid, ra, nullptr);
+        stage_t_load<TB, TM>(B, Nb, m_end, Nb, m_beg, n0, b_vec_ok != 0, opB, ob, tid, rb, want_bias ? csum : nullptr);
+        stage_t_store<TM>(smem, tid, ra);
+        stage_t_store<TM>(smem + 16384, tid, rb);
+    }
+    __syncthreads();
+    for (int mc = 0; mc < nmc; ++mc) {
+        const bool more = mc + 1 < nmc;
+        if (more) {
+            stage_t_load<TA, TM>(A, Ka, m_end, Ka, m_beg + (mc + 1) * MC, k0, a_vec_ok != 0, opA, oa, tid, ra, nullptr);
+            stage_t_load<TB, TM>(B, Nb, m_end, Nb, m_beg + (mc + 1) * MC, n0, b_vec_ok != 0, opB, ob, tid, rb, want_bias ? csum : nullptr);
+        }
+        const char* sa = smem + (mc & 1) * 32768;
+        mma_tile<TM, 1>(sa, sa + 16384, wr, wc, lane, acc);
+        if (more) {
+            char* sn = smem + ((mc + 1) & 1) * 32768;
+            stage_t_store<TM>(sn, tid, ra);
+            stage_t_store<TM>(sn + 16384, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    float* out = slab + (size_t)split * Ka * Nb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = k0 + wr * 64 + 16 * i + 4 * (lane >> 4) + r;
+                const int nn = n0 + wc * 64 + 16 * j + (lane & 15);
+                if (kk < Ka && nn < Nb) out[(size_t)kk * Nb + nn] = acc[i][j][r];
+            }
+
+    if (want_bias) {   // block-reduce the per-thread column sums (uniform branch: kt is per-block)
+        float* red = reinterpret_cast<float*>(smem);       // [groups][128]
+        constexpr int GROUPS = is_bf16_t<TM>::value ? 16 : 8;
+        const int kc = is_bf16_t<TM>::value ? (tid & 15) : (tid & 31);
+        const int mg = is_bf16_t<TM>::value ? (tid >> 4) : (tid >> 5);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[mg * 128 + kc * EPC + e] = csum[e];
+        __syncthreads();
+        if (tid < 128) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) sacc += red[g * 128 + tid];
+            if (n0 + tid < Nb) bias_slab[(size_t)split * Nb + n0 + tid] = sacc;
+        }
+    }
+}
+
+// out[i] += sum_s slab[s*stride + i]
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int splits, size_t stride) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int sidx = 0; sidx < splits; ++sidx) acc += slab[(size_t)sidx * stride + i];
+        out[i] += acc;
+    }
+}
+
+static void tn_plan(int M, int Ka, int Nb, int dtM, int& splits, int& rows_per_split) {
+    const int MC = dtM == DT_BF16 ? 64 : 32;
+    const int tiles = ((Ka + 127) / 128) * ((Nb + 127) / 128);
+    int want = (768 + tiles - 1) / tiles;                 // ~3 workgroups per CU
+    const int maxs = (M + 4 * MC - 1) / (4 * MC);         // at least 4 LDS tiles per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    rows_per_split = ((M + want - 1) / want + MC - 1) / MC * MC;
+    splits = (M + rows_per_split - 1) / rows_per_split;
+}
+
+size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM) {
+    int splits, rps;
+    tn_plan(M, Ka, Nb, dtM, splits, rps);
+    return (size_t)splits * ((size_t)Ka * Nb + Nb);
+}
+
+template <typename TA, typename TB, typename TM>
+static int run_tn(int opA, int opB, const void* A, const void* B, float* out, float* dbias, float* slab,
+                  int M, int Ka, int Nb, int dtM, const OpArgs& oa, const OpArgs& ob, hipStream_t s) {
+    int splits, rps;
+    tn_plan(M, Ka, Nb, dtM, splits, rps);
+    float* bias_slab = dbias ? slab + (size_t)splits * Ka * Nb : nullptr;
+    const int tiles = ((Ka + 127) / 128) * ((Nb + 127) / 128);
+    const int a_ok = (((size_t)Ka * sizeof(TA)) % 16 == 0) && (((uintptr_t)A) % 16 == 0);
+    const int b_ok = (((size_t)Nb * sizeof(TB)) % 16 == 0) && (((uintptr_t)B) % 16 == 0);
+    hipLaunchKernelGGL((gemm_tn_kernel<TA, TB, TM>), dim3(tiles, splits), dim3(256), 0, s,
+                       (const TA*)A, (const TB*)B, slab, bias_slab, M, Ka, Nb, rps, a_ok, b_ok, opA, opB, oa, ob);
+    const int n = Ka * Nb;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s,
+                       (const float*)slab, out, n, splits, (size_t)Ka * Nb);
+    if (dbias)
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((Nb + 255) / 256), dim3(256), 0, s,
+                           (const float*)bias_slab, dbias, Nb, splits, (size_t)Nb);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
+                   float* out, float* dbias, float* slab, int M, int Ka, int Nb,
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s) {
+    if (M <= 0 || Ka <= 0 || Nb <= 0) { ishara_set_error("gemm_tn: bad shape"); return -1; }
+    if (dtA == DT_F32 && dtB == DT_F32 && dtM == DT_F32) return run_tn<float, float, float>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
+    if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<bf16, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
+    if (dtA == DT_F32 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<float, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
+    if (dtA == DT_BF16 && dtB == DT_F32 && dtM == DT_BF16) return run_tn<bf16, float, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
+    ishara_set_error("gemm_tn: unsupported dtype combination %d/%d/%d", dtA, dtB, dtM);
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------
+// weight shadows: Wt[n][k] = W[k][n] (ld ldt) and Wn[k][n] = W[k][n] (ld ldn), zero padded
+// by a preceding memset of the whole shadow arena.
+// ---------------------------------------------------------------------------------
+template <typename TM>
+__global__ void make_shadow_kernel(const float* __restrict__ W, int K, int N, TM* __restrict__ Wt, int ldt, TM* __restrict__ Wn, int ldn) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        float v = 0.f;
+        if (k < K && n < N) { v = W[(size_t)k * N + n]; if (Wn) Wn[(size_t)k * ldn + n] = from_f<TM>(v); }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (Wt) {
+        for (int r = ty; r < 32; r += 8) {
+            const int n = n0 + r, k = k0 + tx;
+            if (k < K && n < N) Wt[(size_t)n * ldt + k] = from_f<TM>(tile[tx][r]);
+        }
+    }
+}
+
+int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt, void* Wn, int ldn, hipStream_t s) {
+    dim3 grid((N + 31) / 32, (K + 31) / 32);
+    if (dtM == DT_BF16) hipLaunchKernelGGL(make_shadow_kernel<bf16>, grid, dim3(256), 0, s, W, K, N, (bf16*)Wt, ldt, (bf16*)Wn, ldn);
+    else hipLaunchKernelGGL(make_shadow_kernel<float>, grid, dim3(256), 0, s, W, K, N, (float*)Wt, ldt, (float*)Wn, ldn);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,131 @@
+// Kernel launchers of the ishara_amd HIP library.  Host-callable; every launch is
+// asynchronous on the given stream, allocates nothing and never synchronises.
+#pragma once
+#include "common.h"
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+static inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+// ---- operand transforms applied while staging a GEMM operand -------------------
+enum : int { OP_NONE = 0, OP_SWISH = 1, OP_COLAFFINE = 2, OP_ROWSCALE = 3, OP_DROPMASK = 4 };
+struct OpArgs {
+    const float* c1 = nullptr;   // OP_COLAFFINE: v*c1[col]+c0[col]
+    const float* c0 = nullptr;
+    const float* rs = nullptr;   // OP_ROWSCALE: v*rs[row / T]
+    int T = 1;
+    DropSpec drop = {0, 0, 1.f}; // OP_DROPMASK: v*mask(row, col)
+};
+
+// ---- GEMM epilogue (NT kernel) ---------------------------------------------------
+enum : int { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+enum : int { DACT_NONE = 0, DACT_SWISH = 1, DACT_POS = 2 };
+enum : int { EPI_STD = 0, EPI_QKV = 1 };
+struct EpiArgs {
+    const float* bias = nullptr;      // [N]
+    const float* addtab = nullptr;    // += addtab[(m % tab_period)*N + n]
+    int tab_period = 1;
+    void* pre_out = nullptr;          // save pre-activation (TC, [M,N])
+    int act = ACT_NONE;
+    DropSpec drop = {0, 0, 1.f};      // elementwise inverted dropout (row=m, col=n)
+    const float* rowscale = nullptr;  // *= rowscale[m / T]
+    int T = 1;
+    int dact = DACT_NONE;             // *= act'(aux[m,n])
+    const void* aux = nullptr;        // TC, [M,N]
+    const void* resid = nullptr;      // TC, [M,N]
+    int mode = EPI_STD;               // EPI_QKV: scatter to q,k [B,H,T,dh] and vt [B,H,dh,T]
+    void* q = nullptr; void* k = nullptr; void* vt = nullptr;
+    int H = 1, dh = 1;
+    int head_major = 1;               // 1: cols = h*3dh + {q,k,v}*dh + i (TF path); 0: {q,k,v}*d + h*dh + i (torch twin)
+};
+
+// C[M,N] = epi( op(A)[M,K] . Bt[N,K]^T ).  Bt is a padded weight shadow: rows padded to
+// a multiple of 128, row stride ldb (elements) a multiple of the K tile (64 bf16 / 32 f32).
+int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
+                   int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s);
+
+// dW[Ka,Nb] += opA(A)[M,Ka]^T . opB(B)[M,Nb]   (fp32 accumulate into `out`, row-major [Ka,Nb]);
+// dbias[Nb] += colsum(opB(B)) when dbias != nullptr.  slab = fp32 scratch of
+// gemm_tn_slab_floats(...) floats.
+size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM);
+int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
+                   float* out, float* dbias, float* slab, int M, int Ka, int Nb,
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s);
+
+// weight shadows: Wt[Np][Kp] (transposed) and Wn[Kp2][Np2] (as-is, padded) in dtM
+int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt, void* Wn, int ldn, hipStream_t s);
+
+// ---- normalisation / conv / small ops (elementwise.hip) ---------------------------
+int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float* beta, float eps,
+                         void* y, float* mean, float* rstd, int M, int C, hipStream_t s);
+// dx = LN'(dy) (+ resid) ; dgamma/dbeta accumulated atomically
+int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd,
+                         const float* gamma, const void* resid, void* dx, float* dgamma, float* dbeta,
+                         int M, int C, hipStream_t s);
+
+enum : int { DWIN_NONE = 0, DWIN_SWISH = 1, DWIN_GLU = 2 };
+// y[b,t,c] = bias[c] + sum_j w[j,c] * in(x)[b, t - padl + j, c]; x has Cin = C (or 2C for GLU).
+// stats: ssum/ssq [B,C] = per-sample sum_t y, sum_t y^2 (fp32 atomics; zero them first; nullptr = off).
+int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const float* bias, void* y,
+                      float* ssum, float* ssq, int B, int T, int C, int k, int padl, hipStream_t s);
+// dx = d in(x) ; dw [k,C], dbias [C] accumulated atomically.
+int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const float* w, void* dx,
+                      float* dw, float* dbias, int B, int T, int C, int k, int padl, hipStream_t s);
+
+// BN finalize from per-sample sums ssum/ssq [nb,C] (count = rows they cover): mean, rstd,
+// a = gamma*rstd, b = beta - mean*a ; moving statistics update when training
+int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* moving_mean, float* moving_var, int training,
+                       float* mean, float* rstd, float* a, float* b, int C, hipStream_t s);
+// ECA fwd on [B,C]: g = a*gap/T + b ; s = sigmoid(conv5(g)) ; P = a*s ; Q = b*s
+int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
+                   float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s);
+// y = x*P[b,c] + Q[b,c] (+ resid)    (P,Q per sample) ; if Q == nullptr -> no offset
+int launch_sample_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y,
+                         int B, int T, int C, hipStream_t s);
+// y = x*a[c] + b[c]
+int launch_col_affine(int dt, const void* x, const float* a, const float* b, void* y, int M, int C, hipStream_t s);
+// per-sample reductions over t: S1[b,c] = sum_t dy ; S2[b,c] = sum_t dy * other   (other optional,
+// normalised as (other-mean[c])*rstd[c] when mean != nullptr)
+int launch_sample_reduce(int dt, const void* dy, const void* other, const float* mean, const float* rstd,
+                         float* S1, float* S2, int B, int T, int C, hipStream_t s);
+// Conv1DBlock BN+ECA backward finalize (one block; small)
+int launch_eca_bn_bwd_finalize(const float* S1, const float* S2, const float* gap, const float* gn, const float* sgate,
+                               const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, int B, int T, int C, hipStream_t s);
+// plain BN backward finalize from per-sample S1,S2: dgamma, dbeta, E[c] = -dbeta/Mtot, Fc = dgamma/Mtot
+int launch_bn_bwd_finalize(const float* S1, const float* S2, float* dgamma, float* dbeta, float* Ecol, float* Fc,
+                           int B, int T, int C, hipStream_t s);
+// dx = a[c] * (dy*sg[b,c] + E[b or 0,c] - xhat*Fc[c]) ; sg optional ; E per-sample if e_per_sample
+int launch_bn_bwd_apply(int dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* a,
+                        const float* sg, const float* E, int e_per_sample, const float* Fc, void* dx,
+                        int B, int T, int C, hipStream_t s);
+// Squeeze-Excite MLP on [B,C]: z = gap/T ; h = swish(z W1 + b1) ; se = sigmoid(h W2 + b2)
+int launch_se_fwd(const float* gap, float invT, const float* W1, const float* b1, const float* W2, const float* b2,
+                  float* hid_pre, float* se, int B, int C, int R, hipStream_t s);
+// given dse[b,c] (= sum_t dOut*u3): grads of W1,b1,W2,b2 (atomic) and dgapT[b,c] = dL/dgap * (1/T)
+int launch_se_bwd(const float* dse, const float* gap, float invT, const float* W1, const float* W2,
+                  const float* hid_pre, const float* se, float* dW1, float* db1, float* dW2, float* db2,
+                  float* dgapT, int B, int C, int R, hipStream_t s);
+
+// ---- attention (attention.hip) -----------------------------------------------------
+// q,k [B,H,T,dh], vt [B,H,dh,T]; o [B*T, H*dh]; lse [B,H,T]
+int launch_attn_fwd(int dt, const void* q, const void* k, const void* vt, void* o, float* lse,
+                    int B, int H, int T, int dh, float scale, DropSpec drop, int impl, hipStream_t s);
+// dqkv [B*T, 3*H*dh] packed like the qkv projection output (head_major flag as in EpiArgs)
+int launch_attn_bwd(int dt, const void* q, const void* k, const void* vt, const void* o, const void* dout,
+                    const float* lse, float* delta, void* dqkv, int B, int H, int T, int dh, float scale,
+                    DropSpec drop, int head_major, int impl, hipStream_t s);
+
+// ---- CTC / decode (ctc.hip) ----------------------------------------------------------
+size_t ctc_workspace_floats(int B, int T, int L);
+// logits [B,T,C] f32; labels [B,L] int64 (padded with blank); nll [B]; dlogits = grad_scale * d nll_b / d logits
+int launch_ctc(const float* logits, const int64_t* labels, int B, int T, int C, int L, int blank,
+               float* nll, float* dlogits, float grad_scale, float* ws, hipStream_t s);
+int launch_mean(const float* v, float* out, int n, float scale, hipStream_t s);
+int launch_greedy_decode(const float* logits, int B, int T, int C, int blank, int* out_idx, int* out_len, hipStream_t s);
+
+// ---- optimizer (optimizer.hip) -----------------------------------------------------------
+struct RAdamArgs { float lr, wd, beta1, beta2, eps, c1, c2, r_t; int rect; int sync; float slow_step; };
+int launch_radam_lookahead(float* theta, const float* grad, float* m, float* v, float* slow, int64_t n,
+                           RAdamArgs a, hipStream_t s);
+int launch_scale(float* x, int64_t n, float scale, hipStream_t s);

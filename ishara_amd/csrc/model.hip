@@ -1,0 +1,818 @@
+// Host side of libishara_hip.so: the layer graph get_model(...) builds
+// (conv-hybrid-model.ipynb c7:12-65), its flat parameter layout, the workspace plan and the
+// forward / backward / optimizer orchestration over the kernels in gemm.hip, elementwise.hip,
+// attention.hip, ctc.hip and optimizer.hip.  Everything is launched on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "kernels.h"
+#include "../../include/ishara_hip.h"
+
+// ------------------------------------------------------------------ error string
+static thread_local char g_err[1024] = "";
+void ishara_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* ishara_last_error(void) { return g_err; }
+
+#define CK(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
+
+static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------ small kernels
+__global__ void droppath_kernel(float* rs, int B, DropSpec d) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) rs[b] = (d.thr == 0u || rng_keep(rng_row_key(d.key, (uint32_t)b), 0u, d.thr)) ? d.scale : 0.f;
+}
+__global__ void dropout_mask_kernel(float* out, int rows, int cols, DropSpec d) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / cols), c = (uint32_t)(i % cols);
+        out[i] = (d.thr == 0u || rng_keep(rng_row_key(d.key, r), c, d.thr)) ? d.scale : 0.f;
+    }
+}
+// packed qkv [M,3d] (head-major) -> q,k [B,H,T,dh], vt [B,H,dh,T]   (operator tests only)
+template <typename T>
+__global__ void qkv_split_kernel(const T* qkv, T* q, T* k, T* vt, int B, int H, int Tn, int dh) {
+    const int d = H * dh;
+    const size_t n = (size_t)B * Tn * 3 * d;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / (3 * d);
+        const int col = (int)(i - m * 3 * d);
+        const int h = col / (3 * dh), w = col - h * 3 * dh, part = w / dh, e = w - part * dh;
+        const int b = (int)(m / Tn), t = (int)(m - (size_t)b * Tn);
+        const T v = qkv[i];
+        if (part == 0) q[((size_t)(b * H + h) * Tn + t) * dh + e] = v;
+        else if (part == 1) k[((size_t)(b * H + h) * Tn + t) * dh + e] = v;
+        else vt[((size_t)(b * H + h) * dh + e) * Tn + t] = v;
+    }
+}
+
+// ------------------------------------------------------------------ model description
+struct ParamEntry { std::string name; int ndim; int64_t shape[2]; int64_t offset; bool trainable; };
+
+struct DenseW {           // a Dense / 1x1-conv weight [K,N] (+bias) with its MFMA shadows
+    int w = -1, b = -1, K = 0, N = 0;
+    size_t wt = 0, wn = 0;    // byte offsets in the workspace
+    int ldt = 0, ldn = 0;
+};
+struct Norm { int gamma = -1, beta = -1; };
+struct BNp { int gamma = -1, beta = -1, mm = -1, mv = -1; };
+
+struct Buf { size_t off = 0; };   // byte offset in the workspace
+
+struct ConvBlock {
+    DenseW W1, W2; int dw = -1, eca = -1; BNp bn; int k = 0; uint32_t site = 0;
+    Buf z1, h2, h4, out, ssum, ssq, mean, rstd, a, bsh, gn, sg, P, Q, rs;
+};
+struct FFN {
+    Norm ln; float eps; DenseW Wa, Wb; uint32_t site_in = 0, site_out = 0; bool has_out_drop = false;
+    Buf xn, mean, rstd, za, u, out;
+};
+struct MHSA {
+    Norm ln; float eps; DenseW Wqkv, Wp; float rate = 0.f; uint32_t site_attn = 0, site_out = 0; bool has_out_drop = false;
+    Buf xn, mean, rstd, q, k, vt, o, lse, out;
+};
+struct SqzConv {
+    Norm ln; DenseW Wc1, Wc3; int dw = -1, seW1 = -1, seb1 = -1, seW2 = -1, seb2 = -1; int k = 0, R = 0;
+    Buf xn, mean, rstd, zc, zd, u3, gap, hid, se, out;
+};
+struct ConfConv {
+    DenseW Wp1, Wp2; int dw = -1, dwb = -1; BNp bn; Norm ln; int k = 0;
+    Buf g, v, ssum, ssq, mean, rstd, a, bsh, r, lnmean, lnrstd, out;
+};
+struct Layer {            // one entry of the sequential graph
+    enum Kind { CONV, SQZ, CONF } kind;
+    int idx;
+};
+struct SqzBlock { FFN ffn1; MHSA mha; SqzConv conv; FFN ffn2; };
+struct ConfBlock { FFN ffn1; MHSA mha; ConfConv conv; FFN ffn2; };
+
+struct ishara_model {
+    ishara_config cfg;
+    int dt;                       // activation / MFMA dtype
+    int d, T, F, C, H, dh, dtop, Bmax, L;
+    std::vector<ParamEntry> entries;
+    int64_t n_total = 0, n_train = 0;
+    // graph
+    DenseW stemW; BNp stem_bn;
+    Buf stem_h0, stem_out, stem_ssum, stem_ssq, stem_mean, stem_rstd, stem_a, stem_bsh, pe;
+    std::vector<ConvBlock> convs;
+    std::vector<SqzBlock> sqz;
+    std::vector<ConfBlock> conf;
+    std::vector<Layer> layers;
+    DenseW topW, clsW; uint32_t head_site = 0; Buf head_hh;
+    uint32_t nsites = 0;
+    std::vector<DenseW*> denses;
+    // temps
+    Buf gA, gB, t1, t2, t3, S1, S2, E, Fc, Ecol, dse, dgapT, slab, ctcws, dlogits, nllb, delta;
+    size_t shadow_begin = 0, shadow_end = 0;
+    size_t ws_need = 0;
+    // bound
+    float* params = nullptr; float* grads = nullptr; float* om = nullptr; float* ov = nullptr; float* oslow = nullptr;
+    char* ws = nullptr; int64_t ws_bytes = 0;
+    std::vector<float> pe_host;
+    // run state
+    int lastB = 0; int last_training = 0; uint32_t last_seed = 0; const float* last_x = nullptr;
+    int opt_iter = 0;
+    hipStream_t s = nullptr;
+
+    // ---- build helpers
+    int addp(const std::string& name, int64_t r, int64_t c, bool trainable) {
+        ParamEntry e; e.name = name; e.ndim = c > 0 ? 2 : 1; e.shape[0] = r; e.shape[1] = c > 0 ? c : 0; e.offset = -1; e.trainable = trainable;
+        entries.push_back(e);
+        return (int)entries.size() - 1;
+    }
+    size_t cur = 0;
+    Buf alloc(size_t bytes) { Buf b; b.off = cur; cur = rup(cur + bytes, 256); return b; }
+    Buf act(int cols) { return alloc((size_t)Bmax * T * cols * dt_size(dt)); }
+    Buf f32(size_t n) { return alloc(n * sizeof(float)); }
+    DenseW dense(const std::string& name, int K, int N, bool bias) {
+        DenseW w; w.K = K; w.N = N;
+        w.w = addp(name + "/kernel", K, N, true);
+        if (bias) w.b = addp(name + "/bias", N, 0, true);
+        return w;
+    }
+    Norm norm(const std::string& name, int c) { Norm n; n.gamma = addp(name + "/gamma", c, 0, true); n.beta = addp(name + "/beta", c, 0, true); return n; }
+    BNp bnp(const std::string& name, int c) {
+        BNp b; b.gamma = addp(name + "/gamma", c, 0, true); b.beta = addp(name + "/beta", c, 0, true);
+        b.mm = addp(name + "/moving_mean", c, 0, false); b.mv = addp(name + "/moving_variance", c, 0, false);
+        return b;
+    }
+    float* P(int idx) const { return params + entries[idx].offset; }
+    float* G(int idx) const { return grads + entries[idx].offset; }
+    template <typename TT = void> TT* W(Buf b) const { return reinterpret_cast<TT*>(ws + b.off); }
+    float* Wf(Buf b) const { return reinterpret_cast<float*>(ws + b.off); }
+};
+
+// ------------------------------------------------------------------ construction
+static void build_conv(ishara_model* m, const std::string& name, int k) {
+    ConvBlock cb;
+    const int d = m->d, c = 2 * d;
+    cb.k = k;
+    cb.W1 = m->dense(name + "_expand_conv", d, c, true);
+    cb.dw = m->addp(name + "_dwconv/depthwise_kernel", k, c, true);
+    cb.bn = m->bnp(name + "_bn", c);
+    cb.eca = m->addp(name + "_eca/kernel", 5, 0, true);
+    cb.W2 = m->dense(name + "_project_conv", c, d, true);
+    cb.site = m->nsites++;
+    m->convs.push_back(cb);
+    m->layers.push_back({Layer::CONV, (int)m->convs.size() - 1});
+}
+static FFN build_ffn(ishara_model* m, Norm ln, float eps, const std::string& n1, const std::string& n2, int e, bool out_drop) {
+    FFN f; f.ln = ln; f.eps = eps;
+    f.Wa = m->dense(n1, m->d, m->d * e, true);
+    f.Wb = m->dense(n2, m->d * e, m->d, true);
+    f.site_in = m->nsites++;
+    f.has_out_drop = out_drop;
+    if (out_drop) f.site_out = m->nsites++;
+    return f;
+}
+static MHSA build_mhsa(ishara_model* m, Norm ln, float eps, const std::string& name, float rate, bool out_drop) {
+    MHSA a; a.ln = ln; a.eps = eps; a.rate = rate;
+    a.Wqkv = m->dense(name + "/qkv", m->d, 3 * m->d, false);
+    a.Wp = m->dense(name + "/proj", m->d, m->d, false);
+    a.site_attn = m->nsites++;
+    a.has_out_drop = out_drop;
+    if (out_drop) a.site_out = m->nsites++;
+    return a;
+}
+
+static void build_graph(ishara_model* m) {
+    const ishara_config& c = m->cfg;
+    const int d = m->d;
+    m->stemW = m->dense("stem_conv", m->F, d, false);
+    m->stem_bn = m->bnp("stem_bn", d);
+    auto conv_blocks = [&](const std::string& tag) {
+        for (int j = 0; j < c.num_conv_per_block; ++j) {
+            const int k = c.kernel_sizes[j % c.num_kernel_sizes];
+            build_conv(m, "conv" + tag + "_" + std::to_string(j + 1), k);
+        }
+    };
+    const int esq = c.squeeze_expansion > 0 ? c.squeeze_expansion : c.expansion_factor;
+    const int ecf = c.conformer_expansion > 0 ? c.conformer_expansion : c.expansion_factor;
+    const int tk = c.transformer_kernel_size;
+    for (int i = 0; i < c.num_conv_squeeze_blocks; ++i) {
+        conv_blocks("squeeze_" + std::to_string(i));
+        const std::string n = "squeezeformer_" + std::to_string(i);
+        SqzBlock sb;
+        // parameter order = oracle/ishara_oracle.py::_squeezeformer_specs
+        Norm n1 = m->norm(n + "/norm1", d);
+        sb.ffn1 = build_ffn(m, n1, 1e-6f, n + "/ffn1_dense1", n + "/ffn1_dense2", esq, true);
+        Norm n2 = m->norm(n + "/norm2", d);
+        sb.mha = build_mhsa(m, n2, 1e-6f, n + "/mha", c.dropout_rate, true);
+        sb.conv.ln = m->norm(n + "/conv/norm", d);
+        sb.conv.k = tk;
+        sb.conv.Wc1 = m->dense(n + "/conv/conv1", d, d * esq, true);
+        sb.conv.dw = m->addp(n + "/conv/conv2/depthwise_kernel", tk, d * esq, true);
+        sb.conv.Wc3 = m->dense(n + "/conv/conv3", d * esq, d, true);
+        sb.conv.R = d / 8 > 1 ? d / 8 : 1;
+        sb.conv.seW1 = m->addp(n + "/conv/se/fc1/kernel", d, sb.conv.R, true);
+        sb.conv.seb1 = m->addp(n + "/conv/se/fc1/bias", sb.conv.R, 0, true);
+        sb.conv.seW2 = m->addp(n + "/conv/se/fc2/kernel", sb.conv.R, d, true);
+        sb.conv.seb2 = m->addp(n + "/conv/se/fc2/bias", d, 0, true);
+        Norm n3 = m->norm(n + "/norm3", d);
+        sb.ffn2 = build_ffn(m, n3, 1e-6f, n + "/ffn2_dense1", n + "/ffn2_dense2", esq, true);
+        m->sqz.push_back(sb);
+        m->layers.push_back({Layer::SQZ, (int)m->sqz.size() - 1});
+    }
+    for (int i = 0; i < c.num_conv_conform_blocks; ++i) {
+        conv_blocks("conform_" + std::to_string(i));
+        const std::string n = "conformer_" + std::to_string(i);
+        ConfBlock cb;
+        // order = _conformer_specs: ffn1, mha, conv (pw1, dw, pw2, bn, ln), ffn2, layer_norm1, layer_norm2
+        Norm dummy;
+        cb.ffn1 = build_ffn(m, dummy, 1e-6f, n + "/ffn1/dense1", n + "/ffn1/dense2", ecf, false);
+        cb.mha = build_mhsa(m, dummy, 1e-6f, n + "/mha", c.conformer_attn_dropout, false);
+        cb.conv.k = tk;
+        cb.conv.Wp1 = m->dense(n + "/conv/pointwise_conv1", d, 2 * d, true);
+        cb.conv.dw = m->addp(n + "/conv/depthwise_conv/kernel", tk, d, true);
+        cb.conv.dwb = m->addp(n + "/conv/depthwise_conv/bias", d, 0, true);
+        cb.conv.Wp2 = m->dense(n + "/conv/pointwise_conv2", d, d, true);
+        cb.conv.bn = m->bnp(n + "/conv/batch_norm", d);
+        cb.conv.ln = m->norm(n + "/conv/layer_norm", d);
+        cb.ffn2 = build_ffn(m, dummy, 1e-6f, n + "/ffn2/dense1", n + "/ffn2/dense2", ecf, false);
+        Norm l1 = m->norm(n + "/layer_norm1", d);
+        Norm l2 = m->norm(n + "/layer_norm2", d);
+        cb.ffn1.ln = l1; cb.mha.ln = l1;      // layer_norm1 is applied twice (c5:324,330)
+        cb.ffn2.ln = l2;
+        // dropout sites were numbered in build order ffn1, mha, ffn2 == forward order
+        m->conf.push_back(cb);
+        m->layers.push_back({Layer::CONF, (int)m->conf.size() - 1});
+    }
+    m->topW = m->dense("top_conv", d, m->dtop, true);
+    m->clsW = m->dense("classifier", m->dtop, m->C, true);
+    m->head_site = m->nsites++;
+
+    // physical offsets: trainable first, then BatchNorm moving statistics
+    int64_t off = 0;
+    for (auto& e : m->entries) if (e.trainable) { e.offset = off; off += e.shape[0] * (e.ndim == 2 ? e.shape[1] : 1); }
+    m->n_train = off;
+    for (auto& e : m->entries) if (!e.trainable) { e.offset = off; off += e.shape[0] * (e.ndim == 2 ? e.shape[1] : 1); }
+    m->n_total = off;
+}
+
+static void plan_shadow(ishara_model* m, DenseW& w) {
+    const int bk = m->dt == DT_BF16 ? 64 : 32;
+    const size_t es = dt_size(m->dt);
+    w.ldt = (int)rup(w.K, bk);
+    w.wt = m->alloc(rup(w.N, 128) * (size_t)w.ldt * es).off;
+    w.ldn = (int)rup(w.N, bk);
+    w.wn = m->alloc(rup(w.K, 128) * (size_t)w.ldn * es).off;
+    m->denses.push_back(&w);
+}
+
+static void plan_workspace(ishara_model* m) {
+    const int d = m->d, B = m->Bmax, T = m->T;
+    const size_t Mx = (size_t)B * T;
+    m->cur = 0;
+    // ---- shadows first (one contiguous arena that sync_weights zero-fills)
+    m->shadow_begin = m->cur;
+    plan_shadow(m, m->stemW);
+    for (auto& cb : m->convs) { plan_shadow(m, cb.W1); plan_shadow(m, cb.W2); }
+    // FFN/MHSA shadows are planned with their activations below; keep the arena contiguous by
+    // planning all shadows before any activation:
+    std::vector<DenseW*> later;
+    for (auto& sb : m->sqz) { later.insert(later.end(), {&sb.ffn1.Wa, &sb.ffn1.Wb, &sb.mha.Wqkv, &sb.mha.Wp, &sb.conv.Wc1, &sb.conv.Wc3, &sb.ffn2.Wa, &sb.ffn2.Wb}); }
+    for (auto& cb : m->conf) { later.insert(later.end(), {&cb.ffn1.Wa, &cb.ffn1.Wb, &cb.mha.Wqkv, &cb.mha.Wp, &cb.conv.Wp1, &cb.conv.Wp2, &cb.ffn2.Wa, &cb.ffn2.Wb}); }
+    later.push_back(&m->topW); later.push_back(&m->clsW);
+    for (DenseW* w : later) plan_shadow(m, *w);
+    m->shadow_end = m->cur;
+    // ---- stem
+    m->pe = m->f32((size_t)T * d);
+    m->stem_h0 = m->act(d); m->stem_out = m->act(d);
+    m->stem_ssum = m->f32((size_t)B * d); m->stem_ssq = m->f32((size_t)B * d);
+    m->stem_mean = m->f32(d); m->stem_rstd = m->f32(d); m->stem_a = m->f32(d); m->stem_bsh = m->f32(d);
+    for (auto& cb : m->convs) {
+        const int c = 2 * d;
+        cb.z1 = m->act(c); cb.h2 = m->act(c); cb.h4 = m->act(c); cb.out = m->act(d);
+        cb.ssum = m->f32((size_t)B * c); cb.ssq = m->f32((size_t)B * c);
+        cb.mean = m->f32(c); cb.rstd = m->f32(c); cb.a = m->f32(c); cb.bsh = m->f32(c);
+        cb.gn = m->f32((size_t)B * c); cb.sg = m->f32((size_t)B * c); cb.P = m->f32((size_t)B * c); cb.Q = m->f32((size_t)B * c);
+        cb.rs = m->f32(B);
+    }
+    auto plan_ffn_act = [&](FFN& f) {
+        f.xn = m->act(d); f.mean = m->f32(Mx); f.rstd = m->f32(Mx);
+        f.za = m->act(f.Wa.N); f.u = m->act(f.Wa.N); f.out = m->act(d);
+    };
+    auto plan_mhsa_act = [&](MHSA& a) {
+        a.xn = m->act(d); a.mean = m->f32(Mx); a.rstd = m->f32(Mx);
+        a.q = m->act(d); a.k = m->act(d); a.vt = m->act(d); a.o = m->act(d);
+        a.lse = m->f32((size_t)B * m->H * T); a.out = m->act(d);
+    };
+    for (auto& sb : m->sqz) {
+        plan_ffn_act(sb.ffn1); plan_mhsa_act(sb.mha);
+        SqzConv& c = sb.conv;
+        const int de = c.Wc1.N;
+        c.xn = m->act(d); c.mean = m->f32(Mx); c.rstd = m->f32(Mx);
+        c.zc = m->act(de); c.zd = m->act(de); c.u3 = m->act(d);
+        c.gap = m->f32((size_t)B * d); c.hid = m->f32((size_t)B * c.R); c.se = m->f32((size_t)B * d); c.out = m->act(d);
+        plan_ffn_act(sb.ffn2);
+    }
+    for (auto& cb : m->conf) {
+        plan_ffn_act(cb.ffn1); plan_mhsa_act(cb.mha);
+        ConfConv& c = cb.conv;
+        c.g = m->act(2 * d); c.v = m->act(d);
+        c.ssum = m->f32((size_t)B * d); c.ssq = m->f32((size_t)B * d);
+        c.mean = m->f32(d); c.rstd = m->f32(d); c.a = m->f32(d); c.bsh = m->f32(d);
+        c.r = m->act(d); c.lnmean = m->f32(Mx); c.lnrstd = m->f32(Mx); c.out = m->act(d);
+        plan_ffn_act(cb.ffn2);
+    }
+    m->head_hh = m->act(m->dtop);
+    // ---- temporaries
+    int maxw = 3 * d;
+    if (m->dtop > maxw) maxw = m->dtop;
+    for (auto& sb : m->sqz) if (sb.ffn1.Wa.N > maxw) maxw = sb.ffn1.Wa.N;
+    for (auto& cb : m->conf) if (cb.ffn1.Wa.N > maxw) maxw = cb.ffn1.Wa.N;
+    m->gA = m->act(d); m->gB = m->act(d);
+    m->t1 = m->act(maxw); m->t2 = m->act(maxw); m->t3 = m->act(maxw);
+    const int maxc = 2 * d > maxw ? 2 * d : maxw;
+    m->S1 = m->f32((size_t)B * maxc); m->S2 = m->f32((size_t)B * maxc); m->E = m->f32((size_t)B * maxc);
+    m->Fc = m->f32(maxc); m->Ecol = m->f32(maxc);
+    m->dse = m->f32((size_t)B * d); m->dgapT = m->f32((size_t)B * d);
+    size_t slabf = 0;
+    for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > slabf) slabf = f; }
+    m->slab = m->f32(slabf);
+    m->ctcws = m->f32(ctc_workspace_floats(B, T, m->L));
+    m->dlogits = m->f32(Mx * m->C);
+    m->nllb = m->f32(B);
+    m->delta = m->f32((size_t)B * m->H * T);
+    m->ws_need = m->cur;
+}
+
+extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
+    if (!cfg || !out) { ishara_set_error("ishara_create: null argument"); return -1; }
+    ishara_config c = *cfg;
+    if (c.dim <= 0 || c.dim % 8 != 0 || c.dim > 512) { ishara_set_error("dim=%d unsupported (multiple of 8, <=512)", c.dim); return -1; }
+    if (c.num_heads <= 0 || c.dim % c.num_heads != 0) { ishara_set_error("dim %% num_heads != 0"); return -1; }
+    const int dh = c.dim / c.num_heads;
+    if (dh != 8 && dh != 16 && dh != 32 && dh != 64) { ishara_set_error("head dim %d unsupported (8,16,32,64)", dh); return -1; }
+    if (c.frames <= 0 || c.frames % 8 != 0 || c.frames > 512) { ishara_set_error("frames=%d unsupported (multiple of 8, <=512)", c.frames); return -1; }
+    if (c.features <= 0) { ishara_set_error("features must be > 0"); return -1; }
+    if (c.num_classes < 2 || c.num_classes > 64) { ishara_set_error("num_classes=%d unsupported (2..64)", c.num_classes); return -1; }
+    if (c.num_kernel_sizes <= 0 && c.num_conv_per_block > 0) { ishara_set_error("kernel_sizes is empty"); return -1; }
+    if (c.num_kernel_sizes > 8) { ishara_set_error("at most 8 kernel sizes"); return -1; }
+    for (int i = 0; i < c.num_kernel_sizes; ++i) if (c.kernel_sizes[i] < 1 || c.kernel_sizes[i] > 31) { ishara_set_error("kernel size %d unsupported (1..31)", c.kernel_sizes[i]); return -1; }
+    if (c.transformer_kernel_size < 1 || c.transformer_kernel_size > 31 || c.transformer_kernel_size % 2 == 0) { ishara_set_error("transformer_kernel_size must be odd, 1..31"); return -1; }
+    if (c.max_batch <= 0) { ishara_set_error("max_batch must be > 0"); return -1; }
+    if (c.dtype != ISHARA_F32 && c.dtype != ISHARA_BF16) { ishara_set_error("dtype must be ISHARA_F32 or ISHARA_BF16"); return -1; }
+    if (c.top_dim <= 0) c.top_dim = 2 * c.dim;
+    if (c.top_dim % 8 != 0) { ishara_set_error("top_dim must be a multiple of 8"); return -1; }
+    if (c.max_label_len <= 0) c.max_label_len = 64;
+    if (c.max_label_len > 255) { ishara_set_error("max_label_len > 255"); return -1; }
+    ishara_model* m = new ishara_model();
+    m->cfg = c; m->dt = c.dtype == ISHARA_BF16 ? DT_BF16 : DT_F32;
+    m->d = c.dim; m->T = c.frames; m->F = c.features; m->C = c.num_classes; m->H = c.num_heads; m->dh = dh;
+    m->dtop = c.top_dim; m->Bmax = c.max_batch; m->L = c.max_label_len;
+    build_graph(m);
+    plan_workspace(m);
+    // positional encoding table (c5:226-235): [sin | cos] halves, fp32 arithmetic
+    m->pe_host.resize((size_t)m->T * m->d);
+    const int half = m->d / 2;
+    for (int t = 0; t < m->T; ++t)
+        for (int i = 0; i < half; ++i) {
+            const float depth = (float)i / (float)half;
+            const float rate = 1.0f / powf(10000.0f, depth);
+            const float ang = (float)t * rate;
+            m->pe_host[(size_t)t * m->d + i] = sinf(ang);
+            m->pe_host[(size_t)t * m->d + half + i] = cosf(ang);
+        }
+    *out = m;
+    return 0;
+}
+extern "C" void ishara_destroy(ishara_model* m) { delete m; }
+extern "C" int64_t ishara_param_total(const ishara_model* m) { return m->n_total; }
+extern "C" int64_t ishara_param_trainable(const ishara_model* m) { return m->n_train; }
+extern "C" int32_t ishara_param_entries(const ishara_model* m) { return (int32_t)m->entries.size(); }
+extern "C" int ishara_param_info(const ishara_model* m, int32_t i, const char** name, int32_t* ndim, int64_t shape[2], int64_t* offset, int32_t* trainable) {
+    if (i < 0 || i >= (int)m->entries.size()) { ishara_set_error("param index out of range"); return -1; }
+    const ParamEntry& e = m->entries[i];
+    if (name) *name = e.name.c_str();
+    if (ndim) *ndim = e.ndim;
+    if (shape) { shape[0] = e.shape[0]; shape[1] = e.shape[1]; }
+    if (offset) *offset = e.offset;
+    if (trainable) *trainable = e.trainable ? 1 : 0;
+    return 0;
+}
+extern "C" int64_t ishara_workspace_bytes(const ishara_model* m) { return (int64_t)m->ws_need; }
+
+extern "C" int ishara_bind(ishara_model* m, float* params, float* grads, float* opt_m, float* opt_v, float* opt_slow, void* workspace, int64_t workspace_bytes) {
+    if (!params || !workspace) { ishara_set_error("ishara_bind: params and workspace are required"); return -1; }
+    if ((size_t)workspace_bytes < m->ws_need) { ishara_set_error("ishara_bind: workspace too small (%lld < %zu)", (long long)workspace_bytes, m->ws_need); return -1; }
+    if (((uintptr_t)workspace) % 256 != 0) { ishara_set_error("ishara_bind: workspace must be 256-byte aligned"); return -1; }
+    m->params = params; m->grads = grads; m->om = opt_m; m->ov = opt_v; m->oslow = opt_slow;
+    m->ws = (char*)workspace; m->ws_bytes = workspace_bytes;
+    HIP_CHECK_RET(hipMemcpy(m->ws + m->pe.off, m->pe_host.data(), m->pe_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int ishara_sync_weights(ishara_model* m, ishara_stream st) {
+    hipStream_t s = (hipStream_t)st;
+    if (!m->ws) { ishara_set_error("not bound"); return -1; }
+    HIP_CHECK_RET(hipMemsetAsync(m->ws + m->shadow_begin, 0, m->shadow_end - m->shadow_begin, s));
+    for (DenseW* w : m->denses)
+        CK(launch_make_shadow(m->dt, m->P(w->w), w->K, w->N, m->ws + w->wt, w->ldt, m->ws + w->wn, w->ldn, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------ GEMM wrappers
+static int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea) {
+    if (w.b >= 0) ea.bias = m->P(w.b);
+    return launch_gemm_nt(dtA, m->dt, dtC, aop, A, m->ws + w.wt, Cc, M, w.N, w.K, w.ldt, oa, ea, m->s);
+}
+static int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea) {
+    return launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s);
+}
+static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M) {
+    return launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s);
+}
+
+struct Run { int B, M, training; uint32_t seed; };
+static DropSpec dspec(const Run& r, uint32_t site, float rate) { return make_drop(r.seed, site, rate, r.training != 0); }
+
+// ------------------------------------------------------------------ module forward
+static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x) {
+    const int d = m->d, c = 2 * d, B = r.B, T = m->T, dt = m->dt;
+    OpArgs no; EpiArgs e1;
+    CK(gemm_fwd(m, cb.W1, x, dt, m->W(cb.z1), dt, r.M, OP_NONE, no, e1));
+    HIP_CHECK_RET(hipMemsetAsync(m->W(cb.ssum), 0, (size_t)B * c * 4, m->s));
+    HIP_CHECK_RET(hipMemsetAsync(m->W(cb.ssq), 0, (size_t)B * c * 4, m->s));
+    CK(launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), B, T, c, cb.k, cb.k - 1, m->s));
+    CK(launch_bn_finalize(m->Wf(cb.ssum), m->Wf(cb.ssq), B, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
+                          m->P(cb.bn.mm), m->P(cb.bn.mv), r.training, m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.bsh), c, m->s));
+    CK(launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s));
+    CK(launch_sample_affine(dt, m->W(cb.h2), m->Wf(cb.P), m->Wf(cb.Q), nullptr, m->W(cb.h4), B, T, c, m->s));
+    const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
+    EpiArgs e2; e2.resid = x;
+    if (ds.thr) {
+        hipLaunchKernelGGL(droppath_kernel, dim3((B + 255) / 256), dim3(256), 0, m->s, m->Wf(cb.rs), B, ds);
+        e2.rowscale = m->Wf(cb.rs); e2.T = T;
+    }
+    CK(gemm_fwd(m, cb.W2, m->W(cb.h4), dt, m->W(cb.out), dt, r.M, OP_NONE, no, e2));
+    return 0;
+}
+
+static int ffn_fwd(ishara_model* m, FFN& f, const Run& r, const void* x) {
+    const int dt = m->dt;
+    OpArgs no;
+    CK(launch_layernorm_fwd(dt, x, m->P(f.ln.gamma), m->P(f.ln.beta), f.eps, m->W(f.xn), m->Wf(f.mean), m->Wf(f.rstd), r.M, m->d, m->s));
+    EpiArgs ea; ea.pre_out = m->W(f.za); ea.act = ACT_SWISH; ea.drop = dspec(r, f.site_in, m->cfg.dropout_rate);
+    CK(gemm_fwd(m, f.Wa, m->W(f.xn), dt, m->W(f.u), dt, r.M, OP_NONE, no, ea));
+    EpiArgs eb; eb.resid = x;
+    if (f.has_out_drop) eb.drop = dspec(r, f.site_out, m->cfg.dropout_rate);
+    CK(gemm_fwd(m, f.Wb, m->W(f.u), dt, m->W(f.out), dt, r.M, OP_NONE, no, eb));
+    return 0;
+}
+
+static int mhsa_fwd(ishara_model* m, MHSA& a, const Run& r, const void* x) {
+    const int dt = m->dt;
+    OpArgs no;
+    CK(launch_layernorm_fwd(dt, x, m->P(a.ln.gamma), m->P(a.ln.beta), a.eps, m->W(a.xn), m->Wf(a.mean), m->Wf(a.rstd), r.M, m->d, m->s));
+    EpiArgs eq; eq.mode = EPI_QKV; eq.q = m->W(a.q); eq.k = m->W(a.k); eq.vt = m->W(a.vt); eq.H = m->H; eq.dh = m->dh; eq.T = m->T; eq.head_major = 1;
+    CK(gemm_fwd(m, a.Wqkv, m->W(a.xn), dt, nullptr, dt, r.M, OP_NONE, no, eq));
+    const float scale = 1.0f / sqrtf((float)m->d);     // self.scale = dim ** -0.5 (c5:95)
+    CK(launch_attn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->Wf(a.lse), r.B, m->H, m->T, m->dh, scale,
+                       dspec(r, a.site_attn, a.rate), m->cfg.attn_impl, m->s));
+    EpiArgs ep; ep.resid = x;
+    if (a.has_out_drop) ep.drop = dspec(r, a.site_out, m->cfg.dropout_rate);
+    CK(gemm_fwd(m, a.Wp, m->W(a.o), dt, m->W(a.out), dt, r.M, OP_NONE, no, ep));
+    return 0;
+}
+
+static int sqzconv_fwd(ishara_model* m, SqzConv& c, const Run& r, const void* x) {
+    const int dt = m->dt, d = m->d, de = c.Wc1.N, B = r.B, T = m->T;
+    OpArgs no; EpiArgs e0;
+    CK(launch_layernorm_fwd(dt, x, m->P(c.ln.gamma), m->P(c.ln.beta), 1e-6f, m->W(c.xn), m->Wf(c.mean), m->Wf(c.rstd), r.M, d, m->s));
+    CK(gemm_fwd(m, c.Wc1, m->W(c.xn), dt, m->W(c.zc), dt, r.M, OP_NONE, no, e0));
+    CK(launch_dwconv_fwd(dt, DWIN_SWISH, m->W(c.zc), m->P(c.dw), nullptr, m->W(c.zd), nullptr, nullptr, B, T, de, c.k, c.k - 1, m->s));
+    CK(gemm_fwd(m, c.Wc3, m->W(c.zd), dt, m->W(c.u3), dt, r.M, OP_SWISH, no, e0));
+    CK(launch_sample_reduce(dt, m->W(c.u3), nullptr, nullptr, nullptr, m->Wf(c.gap), nullptr, B, T, d, m->s));
+    CK(launch_se_fwd(m->Wf(c.gap), 1.f / T, m->P(c.seW1), m->P(c.seb1), m->P(c.seW2), m->P(c.seb2), m->Wf(c.hid), m->Wf(c.se), B, d, c.R, m->s));
+    CK(launch_sample_affine(dt, m->W(c.u3), m->Wf(c.se), nullptr, x, m->W(c.out), B, T, d, m->s));
+    return 0;
+}
+
+static int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x) {
+    const int dt = m->dt, d = m->d, B = r.B, T = m->T;
+    OpArgs no; EpiArgs e0;
+    CK(gemm_fwd(m, c.Wp1, x, dt, m->W(c.g), dt, r.M, OP_NONE, no, e0));
+    HIP_CHECK_RET(hipMemsetAsync(m->W(c.ssum), 0, (size_t)B * d * 4, m->s));
+    HIP_CHECK_RET(hipMemsetAsync(m->W(c.ssq), 0, (size_t)B * d * 4, m->s));
+    CK(launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), B, T, d, c.k, (c.k - 1) / 2, m->s));
+    CK(launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), 1e-3f, 0.99f,
+                          m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s));
+    OpArgs oa; oa.c1 = m->Wf(c.a); oa.c0 = m->Wf(c.bsh);
+    EpiArgs e2; e2.resid = x;
+    CK(gemm_fwd(m, c.Wp2, m->W(c.v), dt, m->W(c.r), dt, r.M, OP_COLAFFINE, oa, e2));
+    CK(launch_layernorm_fwd(dt, m->W(c.r), m->P(c.ln.gamma), m->P(c.ln.beta), 1e-3f, m->W(c.out), m->Wf(c.lnmean), m->Wf(c.lnrstd), r.M, d, m->s));
+    return 0;
+}
+
+extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float* logits, int32_t training, uint32_t seed, ishara_stream st) {
+    if (!m->ws) { ishara_set_error("ishara_forward: model is not bound"); return -1; }
+    if (B <= 0 || B > m->Bmax) { ishara_set_error("ishara_forward: batch %d outside 1..%d", B, m->Bmax); return -1; }
+    m->s = (hipStream_t)st;
+    Run r{B, B * m->T, training, seed};
+    const int dt = m->dt, d = m->d, T = m->T;
+    OpArgs no;
+    // ---- stem: Dense(no bias) + PE, BatchNorm(momentum .95)  (c7:13-17)
+    EpiArgs es; es.addtab = m->Wf(m->pe); es.tab_period = T;
+    CK(gemm_fwd(m, m->stemW, x, DT_F32, m->W(m->stem_h0), dt, r.M, OP_NONE, no, es));
+    CK(launch_sample_reduce(dt, m->W(m->stem_h0), m->W(m->stem_h0), nullptr, nullptr, m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, T, d, m->s));
+    CK(launch_bn_finalize(m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, (float)B * T, m->P(m->stem_bn.gamma), m->P(m->stem_bn.beta), 1e-3f, 0.95f,
+                          m->P(m->stem_bn.mm), m->P(m->stem_bn.mv), training, m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->stem_a), m->Wf(m->stem_bsh), d, m->s));
+    CK(launch_col_affine(dt, m->W(m->stem_h0), m->Wf(m->stem_a), m->Wf(m->stem_bsh), m->W(m->stem_out), r.M, d, m->s));
+    const void* h = m->W(m->stem_out);
+    for (const Layer& L : m->layers) {
+        if (L.kind == Layer::CONV) { ConvBlock& cb = m->convs[L.idx]; CK(conv_fwd(m, cb, r, h)); h = m->W(cb.out); }
+        else if (L.kind == Layer::SQZ) {
+            SqzBlock& sb = m->sqz[L.idx];
+            CK(ffn_fwd(m, sb.ffn1, r, h)); h = m->W(sb.ffn1.out);
+            CK(mhsa_fwd(m, sb.mha, r, h)); h = m->W(sb.mha.out);
+            CK(sqzconv_fwd(m, sb.conv, r, h)); h = m->W(sb.conv.out);
+            CK(ffn_fwd(m, sb.ffn2, r, h)); h = m->W(sb.ffn2.out);
+        } else {
+            ConfBlock& cb = m->conf[L.idx];
+            CK(ffn_fwd(m, cb.ffn1, r, h)); h = m->W(cb.ffn1.out);
+            CK(mhsa_fwd(m, cb.mha, r, h)); h = m->W(cb.mha.out);
+            CK(confconv_fwd(m, cb.conv, r, h)); h = m->W(cb.conv.out);
+            CK(ffn_fwd(m, cb.ffn2, r, h)); h = m->W(cb.ffn2.out);
+        }
+    }
+    // ---- head: Dense(relu) -> Dropout(0.4) -> Dense  (c7:61-63)
+    EpiArgs et; et.act = ACT_RELU; et.drop = dspec(r, m->head_site, m->cfg.head_dropout);
+    CK(gemm_fwd(m, m->topW, h, dt, m->W(m->head_hh), dt, r.M, OP_NONE, no, et));
+    EpiArgs ec;
+    CK(gemm_fwd(m, m->clsW, m->W(m->head_hh), dt, logits, DT_F32, r.M, OP_NONE, no, ec));
+    m->lastB = B; m->last_training = training; m->last_seed = seed; m->last_x = x;
+    return 0;
+}
+
+// ------------------------------------------------------------------ module backward
+// each *_bwd consumes g (grad wrt the module output) and writes gn (grad wrt its input x)
+static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x, const void* g, void* gn) {
+    const int d = m->d, c = 2 * d, B = r.B, T = m->T, dt = m->dt;
+    OpArgs no;
+    const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
+    EpiArgs e1; if (ds.thr) { e1.rowscale = m->Wf(cb.rs); e1.T = T; }
+    CK(gemm_dgrad(m, cb.W2, g, dt, m->W(m->t1), r.M, OP_NONE, no, e1));                        // dh4
+    OpArgs ob; int bop = OP_NONE; if (ds.thr) { ob.rs = m->Wf(cb.rs); ob.T = T; bop = OP_ROWSCALE; }
+    CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, g, dt, bop, ob, r.M));
+    CK(launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
+    CK(launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
+                                  m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), B, T, c, m->s));
+    CK(launch_bn_bwd_apply(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.sg), m->Wf(m->E), 1, m->Wf(m->Fc), m->W(m->t1), B, T, c, m->s));
+    CK(launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, B, T, c, cb.k, cb.k - 1, m->s));
+    EpiArgs e2; e2.resid = g;
+    CK(gemm_dgrad(m, cb.W1, m->W(m->t2), dt, gn, r.M, OP_NONE, no, e2));
+    CK(gemm_wgrad(m, cb.W1, x, dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
+    return 0;
+}
+
+static int ffn_bwd(ishara_model* m, FFN& f, const Run& r, const void* x, const void* g, void* gn) {
+    const int dt = m->dt;
+    OpArgs no;
+    OpArgs oo; int oop = OP_NONE;
+    if (f.has_out_drop) { oo.drop = dspec(r, f.site_out, m->cfg.dropout_rate); if (oo.drop.thr) oop = OP_DROPMASK; }
+    EpiArgs e1; e1.drop = dspec(r, f.site_in, m->cfg.dropout_rate); e1.dact = DACT_SWISH; e1.aux = m->W(f.za);
+    CK(gemm_dgrad(m, f.Wb, g, dt, m->W(m->t1), r.M, oop, oo, e1));                              // dza
+    CK(gemm_wgrad(m, f.Wb, m->W(f.u), dt, OP_NONE, no, g, dt, oop, oo, r.M));
+    EpiArgs e0;
+    CK(gemm_dgrad(m, f.Wa, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));              // dxn
+    CK(gemm_wgrad(m, f.Wa, m->W(f.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    CK(launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(f.mean), m->Wf(f.rstd), m->P(f.ln.gamma), g, gn, m->G(f.ln.gamma), m->G(f.ln.beta), r.M, m->d, m->s));
+    return 0;
+}
+
+static int mhsa_bwd(ishara_model* m, MHSA& a, const Run& r, const void* x, const void* g, void* gn) {
+    const int dt = m->dt;
+    OpArgs no; EpiArgs e0;
+    OpArgs oo; int oop = OP_NONE;
+    if (a.has_out_drop) { oo.drop = dspec(r, a.site_out, m->cfg.dropout_rate); if (oo.drop.thr) oop = OP_DROPMASK; }
+    CK(gemm_dgrad(m, a.Wp, g, dt, m->W(m->t1), r.M, oop, oo, e0));                              // do
+    CK(gemm_wgrad(m, a.Wp, m->W(a.o), dt, OP_NONE, no, g, dt, oop, oo, r.M));
+    const float scale = 1.0f / sqrtf((float)m->d);
+    CK(launch_attn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta), m->W(m->t2),
+                       r.B, m->H, m->T, m->dh, scale, dspec(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, m->s));
+    CK(gemm_dgrad(m, a.Wqkv, m->W(m->t2), dt, m->W(m->t1), r.M, OP_NONE, no, e0));            // dxn
+    CK(gemm_wgrad(m, a.Wqkv, m->W(a.xn), dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
+    CK(launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), r.M, m->d, m->s));
+    return 0;
+}
+
+static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x, const void* g, void* gn) {
+    const int dt = m->dt, d = m->d, de = c.Wc1.N, B = r.B, T = m->T;
+    OpArgs no; EpiArgs e0;
+    CK(launch_sample_reduce(dt, g, m->W(c.u3), nullptr, nullptr, m->Wf(m->S1), m->Wf(m->dse), B, T, d, m->s));   // dse = sum_t g*u3
+    CK(launch_se_bwd(m->Wf(m->dse), m->Wf(c.gap), 1.f / T, m->P(c.seW1), m->P(c.seW2), m->Wf(c.hid), m->Wf(c.se),
+                     m->G(c.seW1), m->G(c.seb1), m->G(c.seW2), m->G(c.seb2), m->Wf(m->dgapT), B, d, c.R, m->s));
+    CK(launch_sample_affine(dt, g, m->Wf(c.se), m->Wf(m->dgapT), nullptr, m->W(m->t1), B, T, d, m->s));           // du3
+    EpiArgs e1; e1.dact = DACT_SWISH; e1.aux = m->W(c.zd);
+    CK(gemm_dgrad(m, c.Wc3, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e1));                                // dzd
+    CK(gemm_wgrad(m, c.Wc3, m->W(c.zd), dt, OP_SWISH, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    CK(launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, B, T, de, c.k, c.k - 1, m->s));   // dzc
+    CK(gemm_dgrad(m, c.Wc1, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // dxn
+    CK(gemm_wgrad(m, c.Wc1, m->W(c.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    CK(launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(c.mean), m->Wf(c.rstd), m->P(c.ln.gamma), g, gn, m->G(c.ln.gamma), m->G(c.ln.beta), r.M, d, m->s));
+    return 0;
+}
+
+static int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn) {
+    const int dt = m->dt, d = m->d, B = r.B, T = m->T;
+    OpArgs no; EpiArgs e0;
+    CK(launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), r.M, d, m->s));   // dr
+    CK(gemm_dgrad(m, c.Wp2, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // d bn(v)
+    OpArgs oa; oa.c1 = m->Wf(c.a); oa.c0 = m->Wf(c.bsh);
+    CK(gemm_wgrad(m, c.Wp2, m->W(c.v), dt, OP_COLAFFINE, oa, m->W(m->t1), dt, OP_NONE, no, r.M));
+    CK(launch_sample_reduce(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
+    CK(launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(c.bn.gamma), m->G(c.bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
+    CK(launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv
+    CK(launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
+    EpiArgs e2; e2.resid = m->W(m->t1);
+    CK(gemm_dgrad(m, c.Wp1, m->W(m->t3), dt, gn, r.M, OP_NONE, no, e2));
+    CK(gemm_wgrad(m, c.Wp1, x, dt, OP_NONE, no, m->W(m->t3), dt, OP_NONE, no, r.M));
+    return 0;
+}
+
+extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const int64_t* labels, int32_t B, float* loss, float* nll, float loss_scale, ishara_stream st) {
+    if (!m->ws || !m->grads) { ishara_set_error("ishara_loss_backward: model is not bound (grads required)"); return -1; }
+    if (B != m->lastB || !m->last_training) { ishara_set_error("ishara_loss_backward: call ishara_forward(training=1) with the same batch first"); return -1; }
+    m->s = (hipStream_t)st;
+    Run r{B, B * m->T, 1, m->last_seed};
+    const int dt = m->dt, d = m->d, T = m->T;
+    OpArgs no; EpiArgs e0;
+    float* nl = nll ? nll : m->Wf(m->nllb);
+    HIP_CHECK_RET(hipMemsetAsync(m->grads, 0, (size_t)m->n_train * sizeof(float), m->s));
+    CK(launch_ctc(logits, labels, B, T, m->C, m->L, m->C - 1, nl, m->Wf(m->dlogits), loss_scale / (float)B, m->Wf(m->ctcws), m->s));
+    if (loss) CK(launch_mean(nl, loss, B, 1.f / (float)B, m->s));
+    // ---- head
+    // input of the head = output of the last layer
+    const void* hin = m->W(m->stem_out);
+    if (!m->layers.empty()) {
+        const Layer& L = m->layers.back();
+        hin = L.kind == Layer::CONV ? m->W(m->convs[L.idx].out) : (L.kind == Layer::SQZ ? m->W(m->sqz[L.idx].ffn2.out) : m->W(m->conf[L.idx].ffn2.out));
+    }
+    EpiArgs eh; eh.drop = dspec(r, m->head_site, m->cfg.head_dropout); eh.dact = DACT_POS; eh.aux = m->W(m->head_hh);
+    CK(gemm_dgrad(m, m->clsW, m->Wf(m->dlogits), DT_F32, m->W(m->t1), r.M, OP_NONE, no, eh));
+    CK(gemm_wgrad(m, m->clsW, m->W(m->head_hh), dt, OP_NONE, no, m->Wf(m->dlogits), DT_F32, OP_NONE, no, r.M));
+    void* g = m->W(m->gA); void* gn = m->W(m->gB);
+    CK(gemm_dgrad(m, m->topW, m->W(m->t1), dt, g, r.M, OP_NONE, no, e0));
+    CK(gemm_wgrad(m, m->topW, hin, dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    // ---- layers in reverse; `in_of` = input activation of each module
+    for (int li = (int)m->layers.size() - 1; li >= 0; --li) {
+        const Layer& L = m->layers[li];
+        const void* lin = m->W(m->stem_out);
+        if (li > 0) {
+            const Layer& Pv = m->layers[li - 1];
+            lin = Pv.kind == Layer::CONV ? m->W(m->convs[Pv.idx].out) : (Pv.kind == Layer::SQZ ? m->W(m->sqz[Pv.idx].ffn2.out) : m->W(m->conf[Pv.idx].ffn2.out));
+        }
+#define STEP(call) do { CK(call); void* _t = g; g = gn; gn = _t; } while (0)
+        if (L.kind == Layer::CONV) { STEP(conv_bwd(m, m->convs[L.idx], r, lin, g, gn)); }
+        else if (L.kind == Layer::SQZ) {
+            SqzBlock& sb = m->sqz[L.idx];
+            STEP(ffn_bwd(m, sb.ffn2, r, m->W(sb.conv.out), g, gn));
+            STEP(sqzconv_bwd(m, sb.conv, r, m->W(sb.mha.out), g, gn));
+            STEP(mhsa_bwd(m, sb.mha, r, m->W(sb.ffn1.out), g, gn));
+            STEP(ffn_bwd(m, sb.ffn1, r, lin, g, gn));
+        } else {
+            ConfBlock& cb = m->conf[L.idx];
+            STEP(ffn_bwd(m, cb.ffn2, r, m->W(cb.conv.out), g, gn));
+            STEP(confconv_bwd(m, cb.conv, r, m->W(cb.mha.out), g, gn));
+            STEP(mhsa_bwd(m, cb.mha, r, m->W(cb.ffn1.out), g, gn));
+            STEP(ffn_bwd(m, cb.ffn1, r, lin, g, gn));
+        }
+#undef STEP
+    }
+    // ---- stem
+    CK(launch_sample_reduce(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
+    CK(launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(m->stem_bn.gamma), m->G(m->stem_bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
+    CK(launch_bn_bwd_apply(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->stem_a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t1), B, T, d, m->s));
+    CK(gemm_wgrad(m, m->stemW, m->last_x, DT_F32, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    return 0;
+}
+
+// ------------------------------------------------------------------ optimizer
+extern "C" int ishara_optimizer_step(ishara_model* m, float lr, float weight_decay, ishara_stream st) {
+    if (!m->om || !m->ov || !m->oslow || !m->grads) { ishara_set_error("ishara_optimizer_step: optimizer slots are not bound"); return -1; }
+    hipStream_t s = (hipStream_t)st;
+    m->opt_iter += 1;
+    const double t = (double)m->opt_iter, b1 = 0.9, b2 = 0.999;
+    const double b1p = pow(b1, t), b2p = pow(b2, t);
+    const double sma_inf = 2.0 / (1.0 - b2) - 1.0;
+    const double sma_t = sma_inf - 2.0 * t * b2p / (1.0 - b2p);
+    RAdamArgs a;
+    a.lr = lr; a.wd = weight_decay; a.beta1 = (float)b1; a.beta2 = (float)b2; a.eps = 1e-7f;
+    a.c1 = (float)(1.0 / (1.0 - b1p)); a.c2 = (float)(1.0 / (1.0 - b2p));
+    a.rect = sma_t >= 4.0 ? 1 : 0;       // sma_threshold = 4 (c7:68)
+    a.r_t = a.rect ? (float)sqrt(fmax((sma_t - 4.0) / (sma_inf - 4.0) * (sma_t - 2.0) / (sma_inf - 2.0) * sma_inf / sma_t, 0.0)) : 0.f;
+    a.sync = (m->opt_iter % 5 == 0) ? 1 : 0;   // Lookahead(sync_period=5, slow_step_size=0.5) (c7:69)
+    a.slow_step = 0.5f;
+    CK(launch_radam_lookahead(m->params, m->grads, m->om, m->ov, m->oslow, m->n_train, a, s));
+    return ishara_sync_weights(m, st);
+}
+extern "C" int32_t ishara_optimizer_iterations(const ishara_model* m) { return m->opt_iter; }
+extern "C" int ishara_optimizer_set_iterations(ishara_model* m, int32_t it) { m->opt_iter = it; return 0; }
+
+// ------------------------------------------------------------------ stand-alone entry points
+extern "C" int ishara_greedy_decode(const float* logits, int32_t B, int32_t T, int32_t C, int32_t blank, int32_t* out_idx, int32_t* out_len, ishara_stream s) {
+    if (T > 4096) { ishara_set_error("greedy_decode: T too large"); return -1; }
+    return launch_greedy_decode(logits, B, T, C, blank, out_idx, out_len, (hipStream_t)s);
+}
+extern "C" int64_t ishara_ctc_workspace_bytes(int32_t B, int32_t T, int32_t L) { return (int64_t)(ctc_workspace_floats(B, T, L) * sizeof(float)); }
+extern "C" int ishara_ctc_loss(const float* logits, const int64_t* labels, int32_t B, int32_t T, int32_t C, int32_t L, int32_t blank,
+                               float* nll, float* dlogits, float grad_scale, void* ws, ishara_stream s) {
+    return launch_ctc(logits, labels, B, T, C, L, blank, nll, dlogits, grad_scale, (float*)ws, (hipStream_t)s);
+}
+extern "C" int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, int32_t cols, float rate, float* out, ishara_stream s) {
+    const DropSpec d = make_drop(seed, site, rate, true);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, out, rows, cols, d);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---- operator tests: dense
+static void op_shadow_layout(int dt, int K, int N, size_t& wt, int& ldt, size_t& wn, int& ldn, size_t& slab, size_t& total, int M) {
+    const int bk = dt == DT_BF16 ? 64 : 32;
+    const size_t es = dt_size(dt);
+    ldt = (int)rup(K, bk); ldn = (int)rup(N, bk);
+    wt = 0;
+    wn = rup(rup(N, 128) * (size_t)ldt * es, 256);
+    slab = wn + rup(rup(K, 128) * (size_t)ldn * es, 256);
+    total = slab + gemm_tn_slab_floats(M, K, N, dt) * sizeof(float);
+}
+extern "C" int64_t ishara_op_scratch_bytes(int32_t M, int32_t K, int32_t N) {
+    size_t wt, wn, slab, total; int ldt, ldn;
+    op_shadow_layout(DT_F32, K, N, wt, ldt, wn, ldn, slab, total, M);
+    return (int64_t)total;
+}
+extern "C" int ishara_op_dense_fwd(int32_t dt, const void* x, const float* Wm, const float* bias, void* y, int32_t M, int32_t K, int32_t N, int32_t act, void* scratch, ishara_stream st) {
+    hipStream_t s = (hipStream_t)st;
+    size_t wt, wn, slab, total; int ldt, ldn;
+    op_shadow_layout(dt, K, N, wt, ldt, wn, ldn, slab, total, M);
+    char* sc = (char*)scratch;
+    HIP_CHECK_RET(hipMemsetAsync(sc, 0, slab, s));
+    CK(launch_make_shadow(dt, Wm, K, N, sc + wt, ldt, sc + wn, ldn, s));
+    OpArgs no; EpiArgs ea; ea.bias = bias; ea.act = act;
+    return launch_gemm_nt(dt, dt, dt, OP_NONE, x, sc + wt, y, M, N, K, ldt, no, ea, s);
+}
+extern "C" int ishara_op_dense_bwd(int32_t dt, const void* x, const float* Wm, const void* dy, void* dx, float* dW, float* db,
+                                   int32_t M, int32_t K, int32_t N, void* scratch, ishara_stream st) {
+    hipStream_t s = (hipStream_t)st;
+    size_t wt, wn, slab, total; int ldt, ldn;
+    op_shadow_layout(dt, K, N, wt, ldt, wn, ldn, slab, total, M);
+    char* sc = (char*)scratch;
+    HIP_CHECK_RET(hipMemsetAsync(sc, 0, slab, s));
+    CK(launch_make_shadow(dt, Wm, K, N, sc + wt, ldt, sc + wn, ldn, s));
+    OpArgs no; EpiArgs ea;
+    CK(launch_gemm_nt(dt, dt, dt, OP_NONE, dy, sc + wn, dx, M, K, N, ldn, no, ea, s));
+    return launch_gemm_tn(dt, dt, dt, OP_NONE, OP_NONE, x, dy, dW, db, (float*)(sc + slab), M, K, N, no, no, s);
+}
+extern "C" int ishara_op_layernorm_fwd(int32_t dt, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int32_t M, int32_t C, ishara_stream s) {
+    return launch_layernorm_fwd(dt, x, gamma, beta, eps, y, mean, rstd, M, C, (hipStream_t)s);
+}
+extern "C" int ishara_op_layernorm_bwd(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, ishara_stream s) {
+    return launch_layernorm_bwd(dt, dy, x, mean, rstd, gamma, nullptr, dx, dgamma, dbeta, M, C, (hipStream_t)s);
+}
+extern "C" int ishara_op_dwconv_fwd(int32_t dt, int32_t inop, const void* x, const float* w, const float* bias, void* y, float* ssum, float* ssq,
+                                    int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {
+    return launch_dwconv_fwd(dt, inop, x, w, bias, y, ssum, ssq, B, T, C, k, padl, (hipStream_t)s);
+}
+extern "C" int ishara_op_dwconv_bwd(int32_t dt, int32_t inop, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,
+                                    int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {
+    return launch_dwconv_bwd(dt, inop, dy, x, w, dx, dw, dbias, B, T, C, k, padl, (hipStream_t)s);
+}
+// scratch layout: q | k | vt | lse | delta
+extern "C" int64_t ishara_op_attn_scratch_bytes(int32_t B, int32_t H, int32_t T, int32_t dh) {
+    const size_t n = (size_t)B * H * T * dh;
+    return (int64_t)(3 * rup(n * 4, 256) + 2 * rup((size_t)B * H * T * 4, 256));
+}
+static void attn_scratch(char* sc, int dt, int B, int H, int T, int dh, void*& q, void*& k, void*& vt, float*& lse, float*& delta) {
+    const size_t n = (size_t)B * H * T * dh;
+    const size_t seg = rup(n * 4, 256);
+    (void)dt;
+    q = sc; k = sc + seg; vt = sc + 2 * seg;
+    lse = (float*)(sc + 3 * seg);
+    delta = (float*)(sc + 3 * seg + rup((size_t)B * H * T * 4, 256));
+}
+extern "C" int ishara_op_attn_fwd(int32_t dt, const void* qkv, void* o, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
+                                  uint32_t seed, uint32_t site, float rate, int32_t impl, void* scratch, ishara_stream st) {
+    hipStream_t s = (hipStream_t)st;
+    void *q, *k, *vt; float *lse, *delta;
+    attn_scratch((char*)scratch, dt, B, H, T, dh, q, k, vt, lse, delta);
+    if (dt == DT_BF16) hipLaunchKernelGGL(qkv_split_kernel<bf16>, dim3(1024), dim3(256), 0, s, (const bf16*)qkv, (bf16*)q, (bf16*)k, (bf16*)vt, B, H, T, dh);
+    else hipLaunchKernelGGL(qkv_split_kernel<float>, dim3(1024), dim3(256), 0, s, (const float*)qkv, (float*)q, (float*)k, (float*)vt, B, H, T, dh);
+    return launch_attn_fwd(dt, q, k, vt, o, lse, B, H, T, dh, scale, make_drop(seed, site, rate, true), impl, s);
+}
+extern "C" int ishara_op_attn_bwd(int32_t dt, const void* o, const void* dout, void* dqkv, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
+                                  uint32_t seed, uint32_t site, float rate, int32_t impl, void* scratch, ishara_stream st) {
+    hipStream_t s = (hipStream_t)st;
+    void *q, *k, *vt; float *lse, *delta;
+    attn_scratch((char*)scratch, dt, B, H, T, dh, q, k, vt, lse, delta);
+    return launch_attn_bwd(dt, q, k, vt, o, dout, lse, delta, dqkv, B, H, T, dh, scale, make_drop(seed, site, rate, true), 1, impl, s);
+}

@@ -1,0 +1,63 @@
+"""Counter-based dropout RNG — CPU restatement of ishara_amd/csrc/rng.h.
+
+TEST INFRASTRUCTURE ONLY (see oracle/README.md): imported by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg, never by the
+product path.
+
+The reference draws its dropout masks from TensorFlow's stateful RNG
+(`tf.keras.layers.Dropout`, conv-hybrid-model.ipynb c5:83,98,164,183), which
+is not reproducible outside TF.  The build therefore defines its own
+counter-based generator so that the HIP kernels and this oracle can produce
+bit-identical masks for any (seed, site, row, col):
+
+    key_site = lowbias32(seed ^ (site * 0x9E3779B9))
+    key_row  = lowbias32(key_site ^ (row * 0x85EBCA6B))
+    r        = lowbias32(key_row ^ col)
+    keep     = r >= floor(rate * 2^32)
+
+Inverted dropout: kept elements are scaled by 1/(1-rate) (Keras semantics).
+"""
+import numpy as np
+
+_M1 = np.uint32(0x7FEB352D)
+_M2 = np.uint32(0x846CA68B)
+
+
+def lowbias32(x):
+    x = np.asarray(x, dtype=np.uint32).copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint32(16)
+        x *= _M1
+        x ^= x >> np.uint32(15)
+        x *= _M2
+        x ^= x >> np.uint32(16)
+    return x
+
+
+def site_key(seed, site):
+    with np.errstate(over="ignore"):
+        return lowbias32(np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(site) * np.uint32(0x9E3779B9)))
+
+
+def threshold(rate):
+    t = int(float(rate) * 4294967296.0)
+    return np.uint32(min(max(t, 0), 0xFFFFFFFF))
+
+
+def keep_mask(seed, site, rows, cols, rate):
+    """Boolean keep-mask of shape [rows, cols] (row = 'hi' index, col = 'lo')."""
+    ks = site_key(seed, site)
+    with np.errstate(over="ignore"):
+        r = np.arange(rows, dtype=np.uint32) * np.uint32(0x85EBCA6B)
+    key_row = lowbias32(ks ^ r)                       # [rows]
+    c = np.arange(cols, dtype=np.uint32)
+    h = lowbias32(key_row[:, None] ^ c[None, :])      # [rows, cols]
+    return h >= threshold(rate)
+
+
+def scaled_mask(seed, site, rows, cols, rate, dtype=np.float32):
+    """Multiplicative inverted-dropout mask (0 or 1/(1-rate))."""
+    if rate <= 0.0:
+        return np.ones((rows, cols), dtype=dtype)
+    k = keep_mask(seed, site, rows, cols, rate)
+    return k.astype(dtype) * dtype(1.0 / (1.0 - rate))

@@ -1,0 +1,172 @@
+"""Whole-path parity: get_model(...) on the HIP library vs the CPU oracle (oracle/ishara_oracle.py)
+on the same seeded weights and inputs — CTC logits, loss, every parameter gradient, BatchNorm
+moving statistics, greedy decode indices, and the RAdam+Lookahead update.
+
+Tolerances (stated per SURVEY §8d / BASELINE.md):
+  f32 mode : logits max-abs-err <= 1e-4 (north_star "fp32 tolerance"); gradients <= 1e-3 relative
+             to each tensor's max; loss <= 1e-5 relative.
+  bf16 mode: bf16 storage of ~40 chained activations; logits max-abs-err <= 0.15, loss <= 2e-2
+             relative, per-tensor gradient relative L2 error <= 0.12.
+The oracle is evaluated in float64.  PARITY UNPINNED against TensorFlow itself (no TF here; the
+reference holds no golden vectors for this path — SURVEY §8c)."""
+import numpy as np
+import pytest
+import torch
+
+from ishara_amd import get_model
+
+pytestmark = pytest.mark.gpu
+
+CFGS = {
+    # BASELINE configs[0]: get_model(dim=64, 1 squeeze + 1 conformer block) on 8 clips, T176 F276
+    "cfg1": dict(dim=64, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(176, 276), B=8),
+    # small-T, ragged feature count, 2 kernel sizes, more heads
+    "tiny": dict(dim=32, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(48, 20), B=3,
+                 kernel_sizes=[5, 3], num_conv_per_block=2, num_heads=4, transformer_kernel_size=7),
+    # dim 128 / dh 16 with e=4 squeezeformer (variant notebooks), no Conv1DBlocks
+    "variant": dict(dim=128, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(64, 36), B=4,
+                    num_conv_per_block=0, squeeze_expansion=4, top_dim=128),
+}
+
+
+def _oracle_cfg(kw, dropout):
+    from oracle import ishara_oracle as O
+    k = {a: b for a, b in kw.items() if a != "B"}
+    if "kernel_sizes" in k:
+        k["kernel_sizes"] = tuple(k["kernel_sizes"])
+    return O.Config(dropout_rate=dropout, head_dropout=0.4 if dropout > 0 else 0.0,
+                    conformer_attn_dropout=0.1 if dropout > 0 else 0.0, **k)
+
+
+def _build(kw, dtype, dropout):
+    k = {a: b for a, b in kw.items() if a != "B"}
+    return get_model(dropout_rate=dropout, head_dropout=0.4 if dropout > 0 else 0.0,
+                     conformer_attn_dropout=0.1 if dropout > 0 else 0.0, dtype=dtype, max_batch=kw["B"], seed=3, **k)
+
+
+def _perturb(model):
+    """Make norm gains/biases and BN moving stats non-trivial so every gradient path is exercised."""
+    g = np.random.default_rng(11)
+    w = model.get_weights()
+    for n in w:
+        leaf = n.rsplit("/", 1)[-1]
+        if leaf in ("gamma",): w[n] = (1.0 + 0.2 * g.standard_normal(w[n].shape)).astype(np.float32)
+        elif leaf in ("beta", "bias"): w[n] = (0.1 * g.standard_normal(w[n].shape)).astype(np.float32)
+        elif leaf == "moving_mean": w[n] = (0.1 * g.standard_normal(w[n].shape)).astype(np.float32)
+        elif leaf == "moving_variance": w[n] = (1.0 + 0.3 * g.random(w[n].shape)).astype(np.float32)
+    model.set_weights(w)
+    return w
+
+
+def _relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CFGS))
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_train_step_parity(name, dtype, dropout):
+    from oracle import ishara_oracle as O
+    kw = CFGS[name]
+    ocfg = _oracle_cfg(kw, dropout)
+    model = _build(kw, dtype, dropout)
+    W = _perturb(model)
+    x, y = O.synthetic_batch(ocfg, kw["B"], seed=1)
+    seed = 4242
+    loss_t, logits_t = model.loss_and_gradients(x, y, seed=seed)
+    torch.cuda.synchronize()
+    loss, logits = float(loss_t.item()), logits_t.cpu().numpy()
+    grads = model.get_gradients()
+    W_after = model.get_weights()
+    ref_loss, ref_logits, ref_grads, ref_stats = O.loss_and_grads(W, x, y, ocfg, training=True, seed=seed, dtype=torch.float64)
+    lerr = float(np.abs(logits - ref_logits).max())
+    if dtype == "f32":
+        assert lerr <= 1e-4, f"logits max-abs-err {lerr:.3e}"
+        assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-4, (loss, ref_loss)
+    else:
+        assert lerr <= 0.15, f"logits max-abs-err {lerr:.3e}"
+        assert abs(loss - ref_loss) <= 2e-2 * abs(ref_loss), (loss, ref_loss)
+    bad = []
+    for n, rg in ref_grads.items():
+        gg = grads[n]
+        if dtype == "f32":
+            e = _relerr(gg, rg)
+            if e > 1e-3 and np.abs(gg - rg).max() > 1e-6: bad.append((n, e))
+        else:
+            e = float(np.linalg.norm(gg - rg) / (np.linalg.norm(rg) + 1e-12))
+            if e > 0.12 and np.linalg.norm(rg) > 1e-4: bad.append((n, e))
+    assert not bad, f"gradient mismatch ({len(bad)}/{len(ref_grads)}): {sorted(bad, key=lambda t: -t[1])[:8]}"
+    # BatchNorm moving statistics were updated in place by the training forward
+    for n, rs in ref_stats.items():
+        tol = 1e-4 if dtype == "f32" else 3e-2
+        assert np.abs(W_after[n] - rs).max() <= tol * (1 + np.abs(rs).max()), n
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_inference_and_decode_parity(dtype):
+    """model(x, training=False) uses the moving statistics; greedy decode indices are identical."""
+    from oracle import ishara_oracle as O
+    kw = CFGS["cfg1"]
+    ocfg = _oracle_cfg(kw, 0.2)
+    model = _build(kw, dtype, 0.2)
+    W = _perturb(model)
+    x, _ = O.synthetic_batch(ocfg, kw["B"], seed=5)
+    logits = model(x, training=False)
+    P = O.to_torch(W, torch.float64, requires_grad=False)
+    with torch.no_grad():
+        ref, _ = O.forward(P, torch.from_numpy(x).double(), ocfg, training=False)
+    ref = ref.numpy()
+    got = logits.cpu().numpy()
+    err = float(np.abs(got - ref).max())
+    assert err <= (1e-4 if dtype == "f32" else 0.15), f"inference logits max-abs-err {err:.3e}"
+    dec = model.decode_batch(logits)
+    for b in range(kw["B"]):
+        want_self = O.decode_phrase(got[b])                 # integer path: bit exact on the same logits
+        assert np.array_equal(dec[b], want_self)
+        top2 = np.sort(ref[b], axis=1)[:, -2:]
+        if dtype == "f32" and (top2[:, 1] - top2[:, 0]).min() > 1e-3:   # no near-tie frame: indices identical to the oracle's
+            assert np.array_equal(dec[b], O.decode_phrase(ref[b]))
+
+
+def test_optimizer_parity():
+    """6 steps of Lookahead(RAdam) (crosses the sync_period=5 boundary) vs the restated algorithm."""
+    from oracle import ishara_oracle as O
+    kw = CFGS["tiny"]
+    ocfg = _oracle_cfg(kw, 0.0)
+    model = _build(kw, "f32", 0.0)
+    x, y = O.synthetic_batch(ocfg, kw["B"], seed=2)
+    nt = model.n_train
+    theta = model.params[:nt].cpu().numpy().copy()
+    st = O.optimizer_init(theta)
+    model.optimizer.learning_rate = 4e-3
+    for step in range(6):
+        model.loss_and_gradients(x, y, seed=step)
+        g = model.grads[:nt].cpu().numpy().copy()
+        model.apply_gradients()
+        theta = O.optimizer_step(theta, g, st, lr=4e-3)
+        got = model.params[:nt].cpu().numpy()
+        assert np.abs(got - theta).max() <= 2e-6 * (1 + np.abs(theta).max()), f"step {step + 1}"
+    assert model.optimizer.iterations == 6
+
+
+def test_fit_surface():
+    """model.fit with the reference's callbacks (c11-c12): LR scheduler + weight-decay callback."""
+    from ishara_amd import Callback, LearningRateScheduler, lrfn
+    from oracle import ishara_oracle as O
+    kw = CFGS["tiny"]
+    ocfg = _oracle_cfg(kw, 0.2)
+    model = _build(kw, "bf16", 0.2)
+    data = [O.synthetic_batch(ocfg, kw["B"], seed=s) for s in range(3)]
+    sched = [lrfn(e, 1, 4e-3, num_training_steps=3) for e in range(3)]
+    seen = []
+
+    class WD(Callback):
+        def on_epoch_begin(self, epoch, logs=None):
+            self.model.optimizer.weight_decay = self.model.optimizer.learning_rate * 0.05
+            seen.append(float(self.model.optimizer.learning_rate.numpy()))
+
+    h = model.fit(data, validation_data=data[:1], epochs=3, callbacks=[LearningRateScheduler(lambda e: sched[e]), WD()], verbose=0)
+    assert np.allclose(seen, sched)
+    assert len(h.history["loss"]) == 3 and np.isfinite(h.history["loss"]).all() and np.isfinite(h.history["val_loss"]).all()
+    assert h.history["loss"][-1] < h.history["loss"][0]      # 9 steps on 3 batches: the CTC loss goes down
+    assert model.optimizer.iterations == 9

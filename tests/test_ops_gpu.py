@@ -1,0 +1,219 @@
+"""Parity of the individual HIP kernels (through the C ABI) against plain torch fp32/fp64
+references of the same op on the same seeded inputs.  f32 mode: tight tolerance (exact-f32
+MFMA / VALU); bf16 mode: inputs are rounded to bf16 first and the tolerance covers the bf16
+output rounding + accumulation-order differences (stated per test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ishara_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
+TOL = {"f32": dict(rtol=2e-4, atol=2e-4), "bf16": dict(rtol=3e-2, atol=3e-2)}
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(a).to("cuda", dtype).contiguous()
+
+
+def close(got, ref, name, rtol, atol):
+    got = got.detach().float().cpu().double()
+    ref = ref.detach().cpu().double()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    worst = float((err - bound).max())
+    assert worst <= 0, f"{name}: max abs err {float(err.max()):.3e} (ref scale {float(ref.abs().max()):.3e}), exceeds tol by {worst:.3e}"
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0)])
+def test_dense_fwd_bwd(lib, dt, M, K, N, act):
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.randn(M, K, generator=g)).to(tdt)
+    W = torch.randn(K, N, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g).to(tdt)
+    Wq = W.to(tdt).float()
+    xd, Wd, bd, dyd = x.cuda().contiguous(), dev(W), dev(b), dy.cuda().contiguous()
+    y = torch.empty(M, N, dtype=tdt, device="cuda")
+    sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
+    scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    _lib.check(lib.ishara_op_dense_fwd(code, _lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(y), M, K, N, act, scp, stream()))
+    ref = x.double() @ Wq.double() + b.double()
+    ref = [ref, ref * torch.sigmoid(ref), torch.relu(ref)][act]
+    close(y, ref, "dense_fwd", **TOL[dt])
+    if act != 0:
+        return
+    dx = torch.empty(M, K, dtype=tdt, device="cuda")
+    dW = torch.zeros(K, N, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    _lib.check(lib.ishara_op_dense_bwd(code, _lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(dyd), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, stream()))
+    close(dx, dy.double() @ Wq.double().t(), "dense_dx", **TOL[dt])
+    wtol = dict(rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * M ** 0.5)
+    close(dW, x.double().t() @ dy.double(), "dense_dW", **wtol)
+    close(db, dy.double().sum(0), "dense_db", **wtol)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,Cc", [(100, 64), (1000, 256), (77, 512)])
+def test_layernorm(lib, dt, M, Cc):
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(Cc)
+    x = (torch.randn(M, Cc, generator=g) * 2 + 0.5).to(tdt)
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    dy = torch.randn(M, Cc, generator=g).to(tdt)
+    xd, dyd = x.cuda(), dy.cuda()
+    y = torch.empty_like(xd)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    _lib.check(lib.ishara_op_layernorm_fwd(code, _lib.ptr(xd), _lib.ptr(dev(gamma)), _lib.ptr(dev(beta)), C.c_float(1e-6), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), M, Cc, stream()))
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = F.layer_norm(xr, (Cc,), gr, br, 1e-6)
+    close(y, ref, "ln_fwd", **TOL[dt])
+    ref.backward(dy.double())
+    dx = torch.empty_like(xd)
+    dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    _lib.check(lib.ishara_op_layernorm_bwd(code, _lib.ptr(dyd), _lib.ptr(xd), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dev(gamma)), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, Cc, stream()))
+    close(dx, xr.grad, "ln_dx", **TOL[dt])
+    rtol = TOL[dt]["rtol"]
+    close(dg, gr.grad, "ln_dgamma", rtol=rtol, atol=TOL[dt]["atol"] * M ** 0.5)
+    close(db, br.grad, "ln_dbeta", rtol=rtol, atol=TOL[dt]["atol"] * M ** 0.5)
+
+
+def _dw_ref(x, w, bias, inop, padl, C_):
+    """x [B,T,Cin] double; depthwise conv reference with the fused input op."""
+    if inop == 1:
+        u = x * torch.sigmoid(x)
+    elif inop == 2:
+        u = x[..., :C_] * torch.sigmoid(x[..., C_:])
+    else:
+        u = x
+    k = w.shape[0]
+    up = F.pad(u.transpose(1, 2), (padl, k - 1 - padl))
+    return F.conv1d(up, w.t().unsqueeze(1), bias, groups=C_).transpose(1, 2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,T,Cc,k,inop,causal", [(3, 176, 128, 11, 1, True), (2, 64, 256, 3, 1, True), (2, 384, 64, 15, 2, False), (2, 40, 8, 5, 0, True), (1, 16, 512, 31, 2, False)])
+def test_dwconv(lib, dt, B, T, Cc, k, inop, causal):
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(T + k)
+    Cin = 2 * Cc if inop == 2 else Cc
+    x = torch.randn(B, T, Cin, generator=g).to(tdt)
+    w = torch.randn(k, Cc, generator=g) / k ** 0.5
+    bias = torch.randn(Cc, generator=g) if not causal else None
+    dy = torch.randn(B, T, Cc, generator=g).to(tdt)
+    padl = k - 1 if causal else (k - 1) // 2
+    xd, dyd, wd = x.cuda(), dy.cuda(), dev(w)
+    bd = dev(bias) if bias is not None else None
+    y = torch.empty(B, T, Cc, dtype=tdt, device="cuda")
+    ssum, ssq = torch.zeros(B, Cc, device="cuda"), torch.zeros(B, Cc, device="cuda")
+    _lib.check(lib.ishara_op_dwconv_fwd(code, inop, _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), _lib.ptr(ssum), _lib.ptr(ssq), B, T, Cc, k, padl, stream()))
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = bias.double().requires_grad_(True) if bias is not None else None
+    ref = _dw_ref(xr, wr, br, inop, padl, Cc)
+    close(y, ref, "dw_fwd", **TOL[dt])
+    close(ssum, ref.sum(1), "dw_ssum", rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * T ** 0.5)
+    close(ssq, (ref ** 2).sum(1), "dw_ssq", rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * T)
+    ref.backward(dy.double())
+    dx = torch.empty(B, T, Cin, dtype=tdt, device="cuda")
+    dw = torch.zeros(k, Cc, device="cuda")
+    dbias = torch.zeros(Cc, device="cuda") if bias is not None else None
+    _lib.check(lib.ishara_op_dwconv_bwd(code, inop, _lib.ptr(dyd), _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dbias), B, T, Cc, k, padl, stream()))
+    close(dx, xr.grad, "dw_dx", **TOL[dt])
+    close(dw, wr.grad, "dw_dw", rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * (B * T) ** 0.5)
+    if bias is not None:
+        close(dbias, br.grad, "dw_dbias", rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * (B * T) ** 0.5)
+
+
+def _attn_ref(qkv, B, H, T, dh, scale, mask):
+    d = H * dh
+    q4 = qkv.view(B, T, H, 3 * dh).permute(0, 2, 1, 3)
+    q, k, v = q4[..., :dh], q4[..., dh:2 * dh], q4[..., 2 * dh:]
+    a = torch.softmax(q @ k.transpose(-1, -2) * scale, -1)
+    if mask is not None:
+        a = a * mask
+    return (a @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,H,T,dh,rate", [(2, 8, 176, 8, 0.0), (2, 4, 64, 32, 0.2), (1, 2, 384, 64, 0.1), (3, 8, 16, 16, 0.0)])
+def test_attention(lib, dt, B, H, T, dh, rate):
+    from oracle import rng
+    code, tdt = DT[dt]
+    d = H * dh
+    g = torch.Generator().manual_seed(T + dh)
+    qkv = torch.randn(B * T, 3 * d, generator=g).to(tdt)
+    dout = torch.randn(B * T, d, generator=g).to(tdt)
+    scale = d ** -0.5 * 4.0     # sharper softmax than the model's to exercise the max tracking
+    seed, site = 1234, 7
+    qd, dd = qkv.cuda(), dout.cuda()
+    o = torch.empty(B * T, d, dtype=tdt, device="cuda")
+    sc = torch.empty(int(lib.ishara_op_attn_scratch_bytes(B, H, T, dh)) + 256, dtype=torch.uint8, device="cuda")
+    scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    _lib.check(lib.ishara_op_attn_fwd(code, _lib.ptr(qd), _lib.ptr(o), B, H, T, dh, C.c_float(scale), seed, site, C.c_float(rate), 0, scp, stream()))
+    mask = None
+    if rate > 0:
+        mask = torch.from_numpy(rng.scaled_mask(seed, site, B * H * T, T, rate, dtype=np.float64)).view(B, H, T, T)
+    qr = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qr, B, H, T, dh, scale, mask)
+    close(o, ref, "attn_fwd", **TOL[dt])
+    ref.backward(dout.double())
+    dqkv = torch.empty(B * T, 3 * d, dtype=tdt, device="cuda")
+    _lib.check(lib.ishara_op_attn_bwd(code, _lib.ptr(o), _lib.ptr(dd), _lib.ptr(dqkv), B, H, T, dh, C.c_float(scale), seed, site, C.c_float(rate), 0, scp, stream()))
+    close(dqkv, qr.grad, "attn_dqkv", **TOL[dt])
+
+
+@pytest.mark.parametrize("B,T,L", [(4, 176, 64), (3, 384, 64), (2, 16, 8)])
+def test_ctc_and_decode(lib, B, T, L):
+    from oracle import ishara_oracle as O
+    Cc = 60
+    g = np.random.default_rng(T)
+    logits = (g.standard_normal((B, T, Cc)) * 2).astype(np.float32)
+    y = np.full((B, L), 59, np.int64)
+    for b in range(B):
+        n = int(g.integers(0 if b == 0 else 1, min(L, (T - 1) // 2) + 1)) if b < B - 1 else min(L, T // 2)
+        y[b, :n] = g.integers(0, 59, n)
+        if n >= 4:
+            y[b, 1] = y[b, 0]          # repeated label needs the blank transition
+    lg = torch.from_numpy(logits).double().requires_grad_(True)
+    ref = O.ctc_nll(torch.from_numpy(y), lg)
+    ref.sum().backward()
+    ld = dev(logits)
+    nll = torch.empty(B, device="cuda")
+    dl = torch.empty(B, T, Cc, device="cuda")
+    ws = torch.empty(int(lib.ishara_ctc_workspace_bytes(B, T, L)), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ishara_ctc_loss(_lib.ptr(ld), _lib.ptr(dev(y, torch.int64)), B, T, Cc, L, 59, _lib.ptr(nll), _lib.ptr(dl), C.c_float(1.0), _lib.ptr(ws), stream()))
+    close(nll, ref, "ctc_nll", rtol=1e-5, atol=1e-3)
+    close(dl, lg.grad, "ctc_grad", rtol=1e-3, atol=2e-5)
+    # greedy decode, bit exact (integer work), including ties and the dropped final run
+    logits[0, :, :] = 0.0                      # all ties -> argmax 0 everywhere -> empty
+    logits[1, -3:, :] = 0.0; logits[1, -3:, 5] = 9.0   # final run of 5s is never emitted
+    ld = dev(logits)
+    idx = torch.empty(B, T, dtype=torch.int32, device="cuda")
+    ln = torch.empty(B, dtype=torch.int32, device="cuda")
+    _lib.check(lib.ishara_greedy_decode(_lib.ptr(ld), B, T, Cc, 59, _lib.ptr(idx), _lib.ptr(ln), stream()))
+    idx, ln = idx.cpu().numpy(), ln.cpu().numpy()
+    for b in range(B):
+        want = O.decode_phrase(logits[b])
+        assert ln[b] == len(want) and np.array_equal(idx[b, :ln[b]], want), f"decode mismatch sample {b}"
+
+
+def test_dropout_mask_matches_oracle_rng(lib):
+    from oracle import rng
+    out = torch.empty(37, 53, device="cuda")
+    _lib.check(lib.ishara_dropout_mask(99, 5, 37, 53, C.c_float(0.3), _lib.ptr(out), stream()))
+    want = rng.scaled_mask(99, 5, 37, 53, 0.3)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert abs(float((out == 0).float().mean()) - 0.3) < 0.05
