@@ -89,6 +89,13 @@ int ishara_optimizer_step(ishara_model* m, float lr, float weight_decay, ishara_
 int32_t ishara_optimizer_iterations(const ishara_model* m);
 int ishara_optimizer_set_iterations(ishara_model* m, int32_t it);
 
+/* HIP-event profiler (no reference counterpart: the reference profiles with %%timeit / Keras
+ * progress bars).  When enabled, every kernel launch of forward / loss_backward /
+ * optimizer_step is bracketed by events on the launch stream; the report is text, one line per
+ * kernel family: "name launches total_ms algorithmic_bytes flops".  Returns bytes written. */
+int ishara_profile_enable(ishara_model* m, int32_t on);
+int ishara_profile_report(ishara_model* m, char* buf, int32_t cap);
+
 /* decode_phrase (c8:4-12) for a batch: out_idx [B,T] int32 (-1 padded), out_len [B]. */
 int ishara_greedy_decode(const float* logits, int32_t B, int32_t T, int32_t C, int32_t blank,
                          int32_t* out_idx, int32_t* out_len, ishara_stream s);
@@ -100,6 +107,9 @@ int ishara_ctc_loss(const float* logits, const int64_t* labels, int32_t B, int32
 /* The dropout mask the kernels draw for (seed, site): out [rows, cols] f32 (0 or 1/(1-rate)). */
 int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, int32_t cols, float rate,
                         float* out, ishara_stream s);
+
+/* tests: 1 = always use the register-staged GEMM kernels (the LDS-DMA kernels are the default) */
+int ishara_debug_force_regstage(int32_t on);
 
 /* ---- single-operator entry points (parity tests of the individual kernels) ------------ */
 /* y = act(x @ W + b): x [M,K] (dtype dt), W [K,N] f32, y [M,N] (dt); scratch >= ishara_op_scratch_bytes */

@@ -48,10 +48,13 @@ SIGNATURES = {
     "ishara_optimizer_step": (C.c_int, [_P, _F, _F, _P]),
     "ishara_optimizer_iterations": (_I32, [_P]),
     "ishara_optimizer_set_iterations": (C.c_int, [_P, _I32]),
+    "ishara_profile_enable": (C.c_int, [_P, _I32]),
+    "ishara_profile_report": (C.c_int, [_P, C.c_char_p, _I32]),
     "ishara_greedy_decode": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "ishara_ctc_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ishara_ctc_loss": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _F, _P, _P]),
     "ishara_dropout_mask": (C.c_int, [_U32, _U32, _I32, _I32, _F, _P, _P]),
+    "ishara_debug_force_regstage": (C.c_int, [_I32]),
     "ishara_op_scratch_bytes": (_I64, [_I32, _I32, _I32]),
     "ishara_op_dense_fwd": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "ishara_op_dense_bwd": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),

@@ -9,38 +9,43 @@
 #include "kernels.h"
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
-#define CTC_NEG (-1e30f)
+#define CTC_NEG (-1e30)
 
-DEVI float lse3(float a, float b, float c) {
-    const float m = fmaxf(a, fmaxf(b, c));
-    if (m <= -1e29f) return CTC_NEG;
-    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+// log(e^a + e^b + e^c) with the running state in fp64 and the transcendentals in fp32: the
+// lattice values reach ~-1500 at T=384 where an fp32 ulp is 1.2e-4 and the drift over T steps
+// reaches 1e-3 relative in the posteriors; fp64 add/max keeps the drift at the 1e-6 level while
+// exp/log only ever see small-magnitude differences.
+DEVI double lse3(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
+    if (m <= -1e29) return CTC_NEG;
+    const float sum = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
+    return m + (double)__logf(sum);
 }
 
-size_t ctc_workspace_floats(int B, int T, int L) { return (size_t)B * T * (2 * L + 1); }
+size_t ctc_workspace_floats(int B, int T, int L) { return 2 * (size_t)B * T * (2 * L + 1); }   // fp64 lattice
 
 __global__ __launch_bounds__(512) void ctc_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                   int Tn, int C, int L, int blank, float* __restrict__ nll,
-                                                  float* __restrict__ dlogits, float grad_scale, float* __restrict__ ws) {
-    extern __shared__ float sh[];
+                                                  float* __restrict__ dlogits, float grad_scale, double* __restrict__ ws) {
+    extern __shared__ double shd[];
     const int Smax = 2 * L + 1;
-    float* lse = sh;                         // [Tn]
-    float* buf = sh + Tn;                    // [2][Smax + 2]  (2 leading / trailing pads)
-    int* ext = reinterpret_cast<int*>(buf + 2 * (Smax + 2));   // [Smax]
+    double* buf = shd;                                   // [2][Smax + 2]
+    float* lse = reinterpret_cast<float*>(buf + 2 * (Smax + 2));   // [Tn]
+    int* ext = reinterpret_cast<int*>(lse + Tn);         // [Smax]
     __shared__ int s_len;
-    __shared__ float s_logp;
+    __shared__ double s_logp;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* lg = logits + (size_t)b * Tn * C;
     const int64_t* lab = labels + (size_t)b * L;
-    float* wsb = ws + (size_t)b * Tn * Smax;
+    double* wsb = ws + (size_t)b * Tn * Smax;
 
     if (tid == 0) { int n = 0; for (int i = 0; i < L; ++i) n += (lab[i] != blank) ? 1 : 0; s_len = n; }
     for (int t = tid; t < Tn; t += blockDim.x) {
-        float m = CTC_NEG;
+        float m = -1e30f;
         for (int c = 0; c < C; ++c) m = fmaxf(m, lg[(size_t)t * C + c]);
         float a = 0.f;
-        for (int c = 0; c < C; ++c) a += __expf(lg[(size_t)t * C + c] - m);
-        lse[t] = m + __logf(a);
+        for (int c = 0; c < C; ++c) a += expf(lg[(size_t)t * C + c] - m);
+        lse[t] = m + logf(a);
     }
     for (int s = tid; s < Smax; s += blockDim.x) ext[s] = (s & 1) ? (int)lab[s >> 1] : blank;
     __syncthreads();
@@ -53,67 +58,67 @@ __global__ __launch_bounds__(512) void ctc_kernel(const float* __restrict__ logi
 
     // ---- phase 1: alpha ----
     {
-        float* p0 = buf + 2;                 // index -2..Smax-1
-        float* p1 = buf + (Smax + 2) + 2;
+        double* p0 = buf + 2;                // index -2..Smax-1
+        double* p1 = buf + (Smax + 2) + 2;
         if (tid < 2) { buf[tid] = CTC_NEG; buf[(Smax + 2) + tid] = CTC_NEG; }
-        float a = CTC_NEG;
-        if (act && (s == 0 || (s == 1 && len > 0))) a = lg[my] - lse[0];
+        double a = CTC_NEG;
+        if (act && (s == 0 || (s == 1 && len > 0))) a = (double)(lg[my] - lse[0]);
         if (s < Smax) { p0[s] = a; wsb[s] = a; }
         __syncthreads();
         for (int t = 1; t < Tn; ++t) {
-            float* prev = (t & 1) ? p0 : p1;
-            float* cur = (t & 1) ? p1 : p0;
-            float v = CTC_NEG;
+            double* prev = (t & 1) ? p0 : p1;
+            double* cur = (t & 1) ? p1 : p0;
+            double v = CTC_NEG;
             if (act) {
-                const float x2 = skip_ok ? prev[s - 2] : CTC_NEG;
+                const double x2 = skip_ok ? prev[s - 2] : CTC_NEG;
                 v = lse3(prev[s], prev[s - 1], x2);
-                if (v > -1e29f) v += lg[(size_t)t * C + my] - lse[t];
+                if (v > -1e29) v += (double)(lg[(size_t)t * C + my] - lse[t]);
             }
             if (s < Smax) { cur[s] = v; wsb[(size_t)t * Smax + s] = v; }
             __syncthreads();
         }
         if (tid == 0) {
-            float* last = ((Tn - 1) & 1) ? p1 : p0;
-            const float aL = last[S - 1], aL1 = (len > 0) ? last[S - 2] : CTC_NEG;
-            const float lp = lse3(aL, aL1, CTC_NEG);
+            double* last = ((Tn - 1) & 1) ? p1 : p0;
+            const double aL = last[S - 1], aL1 = (len > 0) ? last[S - 2] : CTC_NEG;
+            const double lp = lse3(aL, aL1, CTC_NEG);
             s_logp = lp;
-            nll[b] = -lp;
+            nll[b] = (float)(-lp);
         }
         __syncthreads();
     }
-    const float logp = s_logp;
+    const double logp = s_logp;
     // ---- phase 2: beta, posteriors written over alpha ----
     {
-        float* p0 = buf;                     // index 0..Smax+1 (two trailing pads)
-        float* p1 = buf + (Smax + 2);
+        double* p0 = buf;                    // index 0..Smax+1 (two trailing pads)
+        double* p1 = buf + (Smax + 2);
         if (tid < 2) { p0[Smax + tid] = CTC_NEG; p1[Smax + tid] = CTC_NEG; }
         __syncthreads();
-        float bt = CTC_NEG;
+        double bt = CTC_NEG;
         const int tl = Tn - 1;
-        if (act && (s == S - 1 || (s == S - 2 && len > 0))) bt = lg[(size_t)tl * C + my] - lse[tl];
+        if (act && (s == S - 1 || (s == S - 2 && len > 0))) bt = (double)(lg[(size_t)tl * C + my] - lse[tl]);
         if (s < Smax) {
             p0[s] = bt;
-            const float al = wsb[(size_t)tl * Smax + s];
-            const float lpy = lg[(size_t)tl * C + my] - lse[tl];
-            wsb[(size_t)tl * Smax + s] = (act && al > -1e29f && bt > -1e29f) ? __expf(al + bt - lpy - logp) : 0.f;
+            const double al = wsb[(size_t)tl * Smax + s];
+            const double lpy = (double)(lg[(size_t)tl * C + my] - lse[tl]);
+            wsb[(size_t)tl * Smax + s] = (act && al > -1e29 && bt > -1e29) ? (double)__expf((float)(al + bt - lpy - logp)) : 0.0;
         }
         __syncthreads();
         for (int t = Tn - 2, it = 1; t >= 0; --t, ++it) {
-            float* nxt = (it & 1) ? p0 : p1;
-            float* cur = (it & 1) ? p1 : p0;
-            float v = CTC_NEG;
-            float lpy = 0.f;
+            double* nxt = (it & 1) ? p0 : p1;
+            double* cur = (it & 1) ? p1 : p0;
+            double v = CTC_NEG;
+            double lpy = 0.0;
             if (act) {
-                lpy = lg[(size_t)t * C + my] - lse[t];
-                const float x2 = skip_fw ? nxt[s + 2] : CTC_NEG;
-                const float x1 = (s + 1 < S) ? nxt[s + 1] : CTC_NEG;
+                lpy = (double)(lg[(size_t)t * C + my] - lse[t]);
+                const double x2 = skip_fw ? nxt[s + 2] : CTC_NEG;
+                const double x1 = (s + 1 < S) ? nxt[s + 1] : CTC_NEG;
                 v = lse3(nxt[s], x1, x2);
-                if (v > -1e29f) v += lpy;
+                if (v > -1e29) v += lpy;
             }
             if (s < Smax) {
                 cur[s] = v;
-                const float al = wsb[(size_t)t * Smax + s];
-                wsb[(size_t)t * Smax + s] = (act && al > -1e29f && v > -1e29f) ? __expf(al + v - lpy - logp) : 0.f;
+                const double al = wsb[(size_t)t * Smax + s];
+                wsb[(size_t)t * Smax + s] = (act && al > -1e29 && v > -1e29) ? (double)__expf((float)(al + v - lpy - logp)) : 0.0;
             }
             __syncthreads();
         }
@@ -126,12 +131,12 @@ __global__ __launch_bounds__(512) void ctc_kernel(const float* __restrict__ logi
         const int cl = tid & 63, ts = tid >> 6;        // 8 frames in flight x 64 class lanes
         for (int t = ts; t < Tn; t += 8) {
             if (cl < C) {
-                const float* g = wsb + (size_t)t * Smax;
-                float acc = 0.f;
+                const double* g = wsb + (size_t)t * Smax;
+                double acc = 0.0;
                 if (cl == blank) { for (int s2 = 0; s2 < S; s2 += 2) acc += g[s2]; }
                 else { for (int s2 = 1; s2 < S; s2 += 2) if (ext[s2] == cl) acc += g[s2]; }
-                const float sm = __expf(lg[(size_t)t * C + cl] - lse[t]);
-                dl[(size_t)t * C + cl] = grad_scale * (sm - acc);
+                const float sm = expf(lg[(size_t)t * C + cl] - lse[t]);
+                dl[(size_t)t * C + cl] = grad_scale * (sm - (float)acc);
             }
         }
     }
@@ -140,8 +145,8 @@ __global__ __launch_bounds__(512) void ctc_kernel(const float* __restrict__ logi
 int launch_ctc(const float* logits, const int64_t* labels, int B, int T, int C, int L, int blank,
                float* nll, float* dlogits, float grad_scale, float* ws, hipStream_t s) {
     if (2 * L + 1 > 512 || C > 64) { ishara_set_error("ctc: L=%d (max 255) or C=%d (max 64) unsupported", L, C); return -1; }
-    const size_t shmem = (size_t)(T + 2 * (2 * L + 3)) * sizeof(float) + (size_t)(2 * L + 1) * sizeof(int);
-    hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(512), shmem, s, logits, labels, T, C, L, blank, nll, dlogits, grad_scale, ws);
+    const size_t shmem = (size_t)(2 * (2 * L + 3)) * sizeof(double) + (size_t)T * sizeof(float) + (size_t)(2 * L + 1) * sizeof(int);
+    hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(512), shmem, s, logits, labels, T, C, L, blank, nll, dlogits, grad_scale, reinterpret_cast<double*>(ws));
     return LAUNCH_OK();
 }
 

@@ -82,36 +82,48 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     float ga[8], dg[8], db[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ga[e] = act ? gamma[gl * 8 + e] : 0.f; dg[e] = 0.f; db[e] = 0.f; }
-    for (int row = blockIdx.x * RPB + gr; row < M; row += gridDim.x * RPB) {
-        float d[8], xv[8];
-        if (act) { load8(dy + (size_t)row * C + gl * 8, d); load8(x + (size_t)row * C + gl * 8, xv); }
-        else {
+    // two rows in flight per group: 4 x 16-byte loads outstanding per lane
+    const int stride = gridDim.x * RPB;
+    for (int row0 = blockIdx.x * RPB + gr; row0 < M; row0 += 2 * stride) {
+        float d[2][8], xv[2][8], o[2][8];
+        float mu[2], rs[2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { d[e] = 0.f; xv[e] = 0.f; }
-        }
-        const float mu = mean[row], rs = rstd[row];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            xv[e] = act ? (xv[e] - mu) * rs : 0.f;     // xhat
-            dg[e] += d[e] * xv[e];
-            db[e] += d[e];
-            d[e] *= ga[e];
-            s1 += d[e];
-            s2 += d[e] * xv[e];
-        }
-        s1 = group_sum<G>(s1) / (float)C;
-        s2 = group_sum<G>(s2) / (float)C;
-        if (act) {
-            float o[8];
-            if (resid) load8(resid + (size_t)row * C + gl * 8, o);
+        for (int u = 0; u < 2; ++u) {
+            const int row = row0 + u * stride;
+            const bool ok = act && row < M;
+            if (ok) { load8(dy + (size_t)row * C + gl * 8, d[u]); load8(x + (size_t)row * C + gl * 8, xv[u]); }
             else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = 0.f;
+                for (int e = 0; e < 8; ++e) { d[u][e] = 0.f; xv[u][e] = 0.f; }
             }
+            if (resid && ok) load8(resid + (size_t)row * C + gl * 8, o[u]);
+            else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += rs * (d[e] - s1 - xv[e] * s2);
-            store8(dx + (size_t)row * C + gl * 8, o);
+                for (int e = 0; e < 8; ++e) o[u][e] = 0.f;
+            }
+            mu[u] = row < M ? mean[row] : 0.f;
+            rs[u] = row < M ? rstd[row] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = row0 + u * stride;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xv[u][e] = (act && row < M) ? (xv[u][e] - mu[u]) * rs[u] : 0.f;     // xhat
+                dg[e] += d[u][e] * xv[u][e];
+                db[e] += d[u][e];
+                d[u][e] *= ga[e];
+                s1 += d[u][e];
+                s2 += d[u][e] * xv[u][e];
+            }
+            s1 = group_sum<G>(s1) / (float)C;
+            s2 = group_sum<G>(s2) / (float)C;
+            if (act && row < M) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[u][e] += rs[u] * (d[u][e] - s1 - xv[u][e] * s2);
+                store8(dx + (size_t)row * C + gl * 8, o[u]);
+            }
         }
     }
     // reduce dgamma/dbeta over the RPB row groups of the block, then one atomic per channel
@@ -135,7 +147,7 @@ int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mea
     if (C % 8 != 0 || C > 512) { ishara_set_error("layernorm_bwd: C=%d unsupported", C); return -1; }
     const int G = next_pow2(C / 8);
     const int rpb = 256 / G;
-    const int grid = min((M + rpb - 1) / rpb, 1024);
+    const int grid = max(1, min((M + 2 * rpb - 1) / (2 * rpb), 2048));
 #define LN_B(TT, GG) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, GG>), dim3(grid), dim3(256), 0, s, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)resid, (TT*)dx, dgamma, dbeta, M, C)
 #define LN_BG(TT) switch (G) { case 1: LN_B(TT, 1); break; case 2: LN_B(TT, 2); break; case 4: LN_B(TT, 4); break; case 8: LN_B(TT, 8); break; \
                                case 16: LN_B(TT, 16); break; case 32: LN_B(TT, 32); break; default: LN_B(TT, 64); break; }
@@ -468,16 +480,24 @@ int launch_sample_reduce(int dt, const void* dy, const void* other, const float*
 // =====================================================================================
 // BatchNorm finalize from per-sample sums [nb, C] (fp64 accumulation across samples)
 // =====================================================================================
-__global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nb, float count,
+// block = 64 channels x 16 sample lanes; fp64 accumulation across samples
+#define FIN_BL 16
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nb, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ mmean, float* __restrict__ mvar, int training,
                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ bsh, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double rs_[FIN_BL][64], rq_[FIN_BL][64];
+    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (training && c < C)
+        for (int b = bl; b < nb; b += FIN_BL) { s += (double)ssum[(size_t)b * C + c]; q += (double)ssq[(size_t)b * C + c]; }
+    rs_[bl][cl] = s; rq_[bl][cl] = q;
+    __syncthreads();
+    if (bl != 0 || c >= C) return;
     float mu, var;
     if (training) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < nb; ++b) { s += (double)ssum[(size_t)b * C + c]; q += (double)ssq[(size_t)b * C + c]; }
+        for (int i = 1; i < FIN_BL; ++i) { s += rs_[i][cl]; q += rq_[i][cl]; }
         const double m = s / (double)count;
         double v = q / (double)count - m * m;
         if (v < 0.0) v = 0.0;
@@ -494,7 +514,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* 
 int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count, const float* gamma, const float* beta,
                           float eps, float momentum, float* moving_mean, float* moving_var, int training,
                           float* mean, float* rstd, float* a, float* b, int C, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, ssum, ssq, nb, count, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64 * FIN_BL), 0, s, ssum, ssq, nb, count, gamma, beta, eps, momentum,
                        moving_mean, moving_var, training, mean, rstd, a, b, C);
     return LAUNCH_OK();
 }
@@ -533,41 +553,61 @@ int launch_eca_fwd(const float* gap, const float* a, const float* b, const float
 // =====================================================================================
 // y = x*P[b,c] + Q[b,c] (+resid)  /  y = x*a[c] + b[c]
 // =====================================================================================
+// grid = (row blocks, samples); a thread keeps one 8-channel chunk, so the per-sample /
+// per-channel coefficients are loaded once and the row loop is pure 16-byte streaming.
 template <typename T>
 __global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ x, const float* __restrict__ P, const float* __restrict__ Q,
-                                                     const T* __restrict__ resid, T* __restrict__ y, size_t nchunks, int Tn, int C, int per_sample) {
+                                                     const T* __restrict__ resid, T* __restrict__ y, int Tn, int C, int per_sample) {
     const int nch = C >> 3;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = i / nch;
-        const int ch = (int)(i - row * nch) * 8;
-        const size_t pb = per_sample ? (row / Tn) * C + ch : ch;
-        float v[8];
-        load8(x + i * 8, v);
+    const int cpr = min(nch, 256), rpb = 256 / cpr;
+    const int cl = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    const int b = blockIdx.y;
+    if (rl >= rpb) return;
+    for (int chunk = cl; chunk < nch; chunk += cpr) {
+        const float* pp = P + (per_sample ? (size_t)b * C : 0) + chunk * 8;
+        float p[8], q[8];
+        load8(pp, p);
+        if (Q) load8(Q + (per_sample ? (size_t)b * C : 0) + chunk * 8, q);
+        else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * P[pb + e] + (Q ? Q[pb + e] : 0.f);
-        if (resid) {
-            float r[8];
-            load8(resid + i * 8, r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
+            for (int e = 0; e < 8; ++e) q[e] = 0.f;
         }
-        store8(y + i * 8, v);
+        for (int t = blockIdx.x * rpb + rl; t < Tn; t += gridDim.x * rpb) {
+            const size_t off = ((size_t)b * Tn + t) * C + chunk * 8;
+            float v[8];
+            load8(x + off, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * p[e] + q[e];
+            if (resid) {
+                float r[8];
+                load8(resid + off, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            store8(y + off, v);
+        }
     }
 }
 
-static int run_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y, size_t rows, int T, int C, int per_sample, hipStream_t s) {
+static int run_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y, int B, int T, int C, int per_sample, hipStream_t s) {
     if (C % 8 != 0) { ishara_set_error("affine: C%%8 != 0"); return -1; }
-    const size_t nchunks = rows * (C / 8);
-    const int grid = (int)min((nchunks + 255) / 256, (size_t)8192);
-    if (dt == DT_BF16) hipLaunchKernelGGL(affine_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, P, Q, (const bf16*)resid, (bf16*)y, nchunks, T, C, per_sample);
-    else hipLaunchKernelGGL(affine_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, P, Q, (const float*)resid, (float*)y, nchunks, T, C, per_sample);
+    const int cpr = min(C / 8, 256), rpb = 256 / cpr;
+    int gx = (T + rpb - 1) / rpb;
+    const int cap = max(1, 4096 / max(B, 1));
+    if (gx > cap) gx = cap;
+    dim3 grid(gx, B);
+    if (dt == DT_BF16) hipLaunchKernelGGL(affine_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, P, Q, (const bf16*)resid, (bf16*)y, T, C, per_sample);
+    else hipLaunchKernelGGL(affine_kernel<float>, grid, dim3(256), 0, s, (const float*)x, P, Q, (const float*)resid, (float*)y, T, C, per_sample);
     return LAUNCH_OK();
 }
 int launch_sample_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y, int B, int T, int C, hipStream_t s) {
-    return run_affine(dt, x, P, Q, resid, y, (size_t)B * T, T, C, 1, s);
+    return run_affine(dt, x, P, Q, resid, y, B, T, C, 1, s);
 }
 int launch_col_affine(int dt, const void* x, const float* a, const float* b, void* y, int M, int C, hipStream_t s) {
-    return run_affine(dt, x, a, b, nullptr, y, (size_t)M, 1, C, 0, s);
+    // rows are independent: present them as min(M, 256) pseudo-samples for grid parallelism
+    int Bp = 1;
+    for (int cand = 256; cand >= 1; cand >>= 1) if (M % cand == 0) { Bp = cand; break; }
+    return run_affine(dt, x, a, b, nullptr, y, Bp, M / Bp, C, 0, s);
 }
 
 // =====================================================================================
@@ -616,43 +656,62 @@ __global__ __launch_bounds__(256) void eca_bwd_sample_kernel(const float* __rest
     if (threadIdx.x < 5) atomicAdd(dw5 + threadIdx.x, wred[threadIdx.x][0] + wred[threadIdx.x][1] + wred[threadIdx.x][2] + wred[threadIdx.x][3]);
 }
 
-// step 2, per channel: dgamma, dbeta, Fc; E[b,c] <- dgn/T - dbeta/Mtot
-__global__ void eca_bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ gap,
+// step 2, per channel (64 channels x 16 sample lanes per block): dgamma, dbeta, Fc; E[b,c] <- dgn/T - dbeta/Mtot
+__global__ __launch_bounds__(1024) void eca_bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ gap,
                                           const float* __restrict__ sg, const float* __restrict__ mean, const float* __restrict__ rstd,
                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ E, float* __restrict__ Fc,
                                           int B, int Tn, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float invT = 1.f / (float)Tn, mu = mean[c], rs = rstd[c];
+    __shared__ double rg_[FIN_BL][64], rb_[FIN_BL][64];
+    __shared__ float eb_[64];
+    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool act = c < C;
+    const float invT = 1.f / (float)Tn, mu = act ? mean[c] : 0.f, rs = act ? rstd[c] : 0.f;
     double dg = 0.0, db = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const size_t i = (size_t)b * C + c;
-        const float ghat = (gap[i] * invT - mu) * rs;
-        dg += (double)(sg[i] * S2[i] + E[i] * ghat);
-        db += (double)(sg[i] * S1[i] + E[i]);
-    }
+    if (act)
+        for (int b = bl; b < B; b += FIN_BL) {
+            const size_t i = (size_t)b * C + c;
+            const float ghat = (gap[i] * invT - mu) * rs;
+            dg += (double)(sg[i] * S2[i] + E[i] * ghat);
+            db += (double)(sg[i] * S1[i] + E[i]);
+        }
+    rg_[bl][cl] = dg; rb_[bl][cl] = db;
+    __syncthreads();
     const float mtot = (float)B * (float)Tn;
-    dgamma[c] += (float)dg;
-    dbeta[c] += (float)db;
-    Fc[c] = (float)dg / mtot;
-    const float eb = (float)db / mtot;
-    for (int b = 0; b < B; ++b) { const size_t i = (size_t)b * C + c; E[i] = E[i] * invT - eb; }
+    if (bl == 0 && act) {
+        for (int i = 1; i < FIN_BL; ++i) { dg += rg_[i][cl]; db += rb_[i][cl]; }
+        dgamma[c] += (float)dg;
+        dbeta[c] += (float)db;
+        Fc[c] = (float)dg / mtot;
+        eb_[cl] = (float)db / mtot;
+    }
+    __syncthreads();
+    if (act) {
+        const float eb = eb_[cl];
+        for (int b = bl; b < B; b += FIN_BL) { const size_t i = (size_t)b * C + c; E[i] = E[i] * invT - eb; }
+    }
 }
 
 int launch_eca_bn_bwd_finalize(const float* S1, const float* S2, const float* gap, const float* gn, const float* sgate,
                                const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
                                float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, int B, int T, int C, hipStream_t s) {
     hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B), dim3(256), 2 * (C + 4) * sizeof(float), s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5, C);
-    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + 63) / 64), dim3(64), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, B, T, C);
+    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + 63) / 64), dim3(64 * FIN_BL), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, B, T, C);
     return LAUNCH_OK();
 }
 
-__global__ void bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ dgamma,
+__global__ __launch_bounds__(1024) void bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ dgamma,
                                       float* __restrict__ dbeta, float* __restrict__ Ecol, float* __restrict__ Fc, int B, int Tn, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double rg_[FIN_BL][64], rb_[FIN_BL][64];
+    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double dg = 0.0, db = 0.0;
-    for (int b = 0; b < B; ++b) { dg += (double)S2[(size_t)b * C + c]; db += (double)S1[(size_t)b * C + c]; }
+    if (c < C)
+        for (int b = bl; b < B; b += FIN_BL) { dg += (double)S2[(size_t)b * C + c]; db += (double)S1[(size_t)b * C + c]; }
+    rg_[bl][cl] = dg; rb_[bl][cl] = db;
+    __syncthreads();
+    if (bl != 0 || c >= C) return;
+    for (int i = 1; i < FIN_BL; ++i) { dg += rg_[i][cl]; db += rb_[i][cl]; }
     const float mtot = (float)B * (float)Tn;
     dgamma[c] += (float)dg;
     dbeta[c] += (float)db;
@@ -662,32 +721,45 @@ __global__ void bn_bwd_channel_kernel(const float* __restrict__ S1, const float*
 
 int launch_bn_bwd_finalize(const float* S1, const float* S2, float* dgamma, float* dbeta, float* Ecol, float* Fc,
                            int B, int T, int C, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_channel_kernel, dim3((C + 63) / 64), dim3(64), 0, s, S1, S2, dgamma, dbeta, Ecol, Fc, B, T, C);
+    hipLaunchKernelGGL(bn_bwd_channel_kernel, dim3((C + 63) / 64), dim3(64 * FIN_BL), 0, s, S1, S2, dgamma, dbeta, Ecol, Fc, B, T, C);
     return LAUNCH_OK();
 }
 
-// dx = a[c] * (dy*sg[b,c] + E - xhat*Fc[c])
+// dx = a[c] * (dy*sg[b,c] + E - xhat*Fc[c]) = dy*k1 + k0 - x*k2 with per-(sample,channel) constants
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ a, const float* __restrict__ sg,
                                                            const float* __restrict__ E, int e_per_sample, const float* __restrict__ Fc,
-                                                           T* __restrict__ dx, size_t nchunks, int Tn, int C) {
+                                                           T* __restrict__ dx, int Tn, int C) {
     const int nch = C >> 3;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = i / nch;
-        const int ch = (int)(i - row * nch) * 8;
-        const size_t sb = (row / Tn) * C + ch;
-        float d[8], xv[8];
-        load8(dy + i * 8, d);
-        load8(x + i * 8, xv);
+    const int cpr = min(nch, 256), rpb = 256 / cpr;
+    const int cl = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    const int b = blockIdx.y;
+    if (rl >= rpb) return;
+    for (int chunk = cl; chunk < nch; chunk += cpr) {
+        const int ch = chunk * 8;
+        float k0[8], k1[8], k2[8];
+        {
+            float mu[8], rs[8], aa[8], fc[8], ee[8], g[8];
+            load8(mean + ch, mu); load8(rstd + ch, rs); load8(a + ch, aa); load8(Fc + ch, fc);
+            load8(E + (e_per_sample ? (size_t)b * C : 0) + ch, ee);
+            if (sg) load8(sg + (size_t)b * C + ch, g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xh = (xv[e] - mean[ch + e]) * rstd[ch + e];
-            const float g = sg ? sg[sb + e] : 1.f;
-            const float ee = e_per_sample ? E[sb + e] : E[ch + e];
-            d[e] = a[ch + e] * (d[e] * g + ee - xh * Fc[ch + e]);
+            for (int e = 0; e < 8; ++e) {
+                k2[e] = aa[e] * rs[e] * fc[e];
+                k1[e] = aa[e] * (sg ? g[e] : 1.f);
+                k0[e] = aa[e] * ee[e] + mu[e] * k2[e];
+            }
         }
-        store8(dx + i * 8, d);
+        for (int t = blockIdx.x * rpb + rl; t < Tn; t += gridDim.x * rpb) {
+            const size_t off = ((size_t)b * Tn + t) * C + ch;
+            float d[8], xv[8];
+            load8(dy + off, d);
+            load8(x + off, xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = d[e] * k1[e] + k0[e] - xv[e] * k2[e];
+            store8(dx + off, d);
+        }
     }
 }
 
@@ -695,10 +767,13 @@ int launch_bn_bwd_apply(int dt, const void* dy, const void* x, const float* mean
                         const float* sg, const float* E, int e_per_sample, const float* Fc, void* dx,
                         int B, int T, int C, hipStream_t s) {
     if (C % 8 != 0) { ishara_set_error("bn_bwd_apply: C%%8 != 0"); return -1; }
-    const size_t nchunks = (size_t)B * T * (C / 8);
-    const int grid = (int)min((nchunks + 255) / 256, (size_t)8192);
-    if (dt == DT_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, mean, rstd, a, sg, E, e_per_sample, Fc, (bf16*)dx, nchunks, T, C);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, mean, rstd, a, sg, E, e_per_sample, Fc, (float*)dx, nchunks, T, C);
+    const int cpr = min(C / 8, 256), rpb = 256 / cpr;
+    int gx = (T + rpb - 1) / rpb;
+    const int cap = max(1, 4096 / max(B, 1));
+    if (gx > cap) gx = cap;
+    dim3 grid(gx, B);
+    if (dt == DT_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, mean, rstd, a, sg, E, e_per_sample, Fc, (bf16*)dx, T, C);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, mean, rstd, a, sg, E, e_per_sample, Fc, (float*)dx, T, C);
     return LAUNCH_OK();
 }
 

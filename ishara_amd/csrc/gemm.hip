@@ -344,6 +344,177 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const TA* __restrict__ A, 
     }
 }
 
+// ---------------------------------------------------------------------------------
+// NT kernel, LDS-DMA pipelined (the common case: A and Bt both of the MFMA type, no operand
+// transform, K a multiple of the K tile).  Tile 64(M) x 128(N); 4 waves (2x2), wave tile
+// 32x64 = 2x4 MFMA 16x16.  A 3-deep LDS ring is filled by global_load_lds_dwordx4 — no VGPR
+// staging, no ds_write; the XOR swizzle is applied to the per-lane SOURCE address because
+// the LDS side of an LDS-DMA is lane-linear — so two K tiles stay in flight while a third is
+// consumed: one raw s_barrier and one counted s_waitcnt vmcnt(6) per K tile.  Each wave then
+// drains its accumulators through a private fp32 LDS stage (no block barrier) into the fused
+// epilogue with 16-byte coalesced stores.
+// ---------------------------------------------------------------------------------
+#define GL_STAGE 24576          // A 64 rows x 128 B + B 128 rows x 128 B
+#define GL_NSTAGE 3
+
+template <typename TM>
+DEVI void glds_issue(const TM* __restrict__ A, const TM* __restrict__ Bt, int M, int K, int ldb, int m0, int n0, int kt,
+                     char* stage, int wid, int lane) {
+    constexpr int EPC = MmaCfg<TM>::EPC, BK = MmaCfg<TM>::BK;
+    const int r = lane >> 3, sp = lane & 7;
+    const int kcol = kt * BK + ((sp ^ r) * EPC);          // logical 16-byte slot that lands in physical slot sp of row r
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                          // A: 8 pieces of 8 rows; wave takes pieces wid, wid+4
+        const int j = wid + 4 * u;
+        const int row = min(m0 + 8 * j + r, M - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)row * K + kcol),
+                                         (__attribute__((address_space(3))) void*)(stage + j * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                          // B: 16 pieces; wave takes wid, wid+4, wid+8, wid+12
+        const int j = wid + 4 * u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bt + (size_t)(n0 + 8 * j + r) * ldb + kcol),
+                                         (__attribute__((address_space(3))) void*)(stage + 8192 + j * 1024), 16, 0, 0);
+    }
+}
+
+template <typename TM>
+DEVI void mma_tile_2x4(const char* ldsA, const char* ldsB, int wr, int wc, int lane, f32x4 (&acc)[2][4]) {
+    const int r = lane & 15, g = lane >> 4;
+    if constexpr (is_bf16_t<TM>::value) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wr * 32 + 16 * i + r;
+                a[i] = *reinterpret_cast<const bf16x8*>(ldsA + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wc * 64 + 16 * j + r;
+                b[j] = *reinterpret_cast<const bf16x8*>(ldsB + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wr * 32 + 16 * i + r;
+                a[i] = *reinterpret_cast<const float*>(ldsA + row * 128 + ((s ^ (row & 7)) << 4) + g * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wc * 64 + 16 * j + r;
+                b[j] = *reinterpret_cast<const float*>(ldsB + row * 128 + ((s ^ (row & 7)) << 4) + g * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+template <typename TM, typename TC>
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const TM* __restrict__ A, const TM* __restrict__ Bt, TC* __restrict__ C,
+                                                           int M, int N, int K, int ldb, EpiArgs ea) {
+    __shared__ __attribute__((aligned(16))) char smem[GL_NSTAGE * GL_STAGE];
+    constexpr int BK = MmaCfg<TM>::BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int nMt = (M + 63) >> 6, nNt = (N + 127) >> 7;
+    int mt, nt;
+    {
+        const int id = blockIdx.x;
+        if ((nMt & 7) == 0) { const int xcd = id & 7, local = id >> 3; mt = (local / nNt) * 8 + xcd; nt = local % nNt; }
+        else { mt = id / nNt; nt = id % nNt; }
+    }
+    const int m0 = mt << 6, n0 = nt << 7;
+    const int nk = K / BK;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, 0, smem, wid, lane);
+    if (nk > 1) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, 1, smem + GL_STAGE, wid, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // this wave's pieces of tile kt have landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                          // ... and everyone else's; tile kt-1 fully consumed
+        if (kt + 2 < nk) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, kt + 2, smem + ((kt + 2) % GL_NSTAGE) * GL_STAGE, wid, lane);
+        const char* st = smem + (kt % GL_NSTAGE) * GL_STAGE;
+        mma_tile_2x4<TM>(st, st + 8192, wr, wc, lane, acc);
+    }
+    __syncthreads();     // ring is free: reuse it as four wave-private fp32 stages
+
+    constexpr int SLD = 68;
+    float* stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                stage[(16 * i + 4 * (lane >> 4) + r) * SLD + 16 * j + (lane & 15)] = acc[i][j][r];
+    const int mw = m0 + wr * 32, nw = n0 + wc * 64;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const int c = lane + 64 * qq, row = c >> 3, col = (c & 7) * 8;
+        const int m = mw + row, n = nw + col;
+        if (m < M && n < N) {
+            float v[8];
+            const float4 x0 = *reinterpret_cast<const float4*>(stage + row * SLD + col);
+            const float4 x1 = *reinterpret_cast<const float4*>(stage + row * SLD + col + 4);
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+            epilogue_chunk<TC>(v, m, n, min(8, N - n), N, ea, C);
+        }
+    }
+    if (ea.mode == EPI_QKV) {
+        const int d = ea.H * ea.dh;
+        const int n = nw + lane;
+        if (n < N) {
+            int h, part, i;
+            if (ea.head_major) { h = n / (3 * ea.dh); const int w = n - h * 3 * ea.dh; part = w / ea.dh; i = w - part * ea.dh; }
+            else { part = n / d; const int w = n - part * d; h = w / ea.dh; i = w - h * ea.dh; }
+            if (part == 2) {
+                const float bias = ea.bias ? ea.bias[n] : 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int mb = mw + 8 * rg;
+                    if (mb < M) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = stage[(8 * rg + e) * SLD + lane] + bias;
+                        const int b = mb / ea.T, t = mb - b * ea.T;
+                        TC* dst = reinterpret_cast<TC*>(ea.vt) + ((size_t)(b * ea.H + h) * ea.dh + i) * ea.T + t;
+                        store8_n(dst, v, min(8, M - mb));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename TM, typename TC>
+static int run_nt_glds(const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s) {
+    const int nMt = (M + 63) / 64, nNt = (N + 127) / 128;
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<TM, TC>), dim3(nMt * nNt), dim3(256), 0, s, (const TM*)A, (const TM*)Bt, (TC*)C, M, N, K, ldb, ea);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <typename TA, typename TM, typename TC, int OP>
 static int run_nt(const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s) {
     const int nMt = (M + 127) / 128, nNt = (N + 127) / 128;
@@ -364,11 +535,19 @@ static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int 
     }
 }
 
+int g_force_regstage = 0;   // tests: force the register-staged kernels
+
 int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
                    int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) { ishara_set_error("gemm_nt: bad shape %d %d %d", M, N, K); return -1; }
     if (ea.mode == EPI_QKV && (ea.T % 8 != 0 || N % 8 != 0 || ea.dh % 8 != 0)) {
         ishara_set_error("gemm_nt: QKV split needs T, dh multiples of 8 (T=%d dh=%d)", ea.T, ea.dh); return -1;
+    }
+    const int bk = dtM == DT_BF16 ? 64 : 32;
+    if (op == OP_NONE && dtA == dtM && K % bk == 0 && ((uintptr_t)A) % 16 == 0 && !g_force_regstage) {
+        if (dtM == DT_F32 && dtC == DT_F32) return run_nt_glds<float, float>(A, Bt, C, M, N, K, ldb, ea, s);
+        if (dtM == DT_BF16 && dtC == DT_BF16) return run_nt_glds<bf16, bf16>(A, Bt, C, M, N, K, ldb, ea, s);
+        if (dtM == DT_BF16 && dtC == DT_F32) return run_nt_glds<bf16, float>(A, Bt, C, M, N, K, ldb, ea, s);
     }
     if (dtA == DT_F32 && dtM == DT_F32 && dtC == DT_F32) return run_nt_op<float, float, float>(op, A, Bt, C, M, N, K, ldb, oa, ea, s);
     if (dtA == DT_BF16 && dtM == DT_BF16 && dtC == DT_BF16) return run_nt_op<bf16, bf16, bf16>(op, A, Bt, C, M, N, K, ldb, oa, ea, s);
@@ -529,13 +708,47 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TA* __restrict__ A, 
     }
 }
 
-// out[i] += sum_s slab[s*stride + i]
-__global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int splits, size_t stride) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float acc = 0.f;
-        for (int sidx = 0; sidx < splits; ++sidx) acc += slab[(size_t)sidx * stride + i];
-        out[i] += acc;
+// out[i] += sum_s slab[s*stride + i].  grid = (n/4/256, split groups): each block sums its
+// subset of splits with 4 independent 16-byte loads in flight and issues one atomic per element.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int n, int splits, size_t stride) {
+    const int i4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    const int per = (splits + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = min(splits, s0 + per);
+    if (i4 + 4 <= n && (stride & 3) == 0) {
+        float4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sidx = s0;
+        for (; sidx + 4 <= s1; sidx += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)(sidx + u) * stride + i4);
+                acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+            }
+        }
+        for (; sidx < s1; ++sidx) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)sidx * stride + i4);
+            acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        }
+        atomicAdd(out + i4, (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x));
+        atomicAdd(out + i4 + 1, (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y));
+        atomicAdd(out + i4 + 2, (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z));
+        atomicAdd(out + i4 + 3, (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w));
+    } else {
+        for (int e = 0; e < 4 && i4 + e < n; ++e) {
+            float acc = 0.f;
+            for (int sidx = s0; sidx < s1; ++sidx) acc += slab[(size_t)sidx * stride + i4 + e];
+            atomicAdd(out + i4 + e, acc);
+        }
     }
+}
+
+static void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s) {
+    const int gx = (n + 1023) / 1024;
+    int gy = max(1, min(splits / 4, 2048 / max(gx, 1)));
+    if (gy > 16) gy = 16;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, gy), dim3(256), 0, s, slab, out, n, splits, stride);
 }
 
 static void tn_plan(int M, int Ka, int Nb, int dtM, int& splits, int& rows_per_split) {
@@ -566,12 +779,8 @@ static int run_tn(int opA, int opB, const void* A, const void* B, float* out, fl
     const int b_ok = (((size_t)Nb * sizeof(TB)) % 16 == 0) && (((uintptr_t)B) % 16 == 0);
     hipLaunchKernelGGL((gemm_tn_kernel<TA, TB, TM>), dim3(tiles, splits), dim3(256), 0, s,
                        (const TA*)A, (const TB*)B, slab, bias_slab, M, Ka, Nb, rps, a_ok, b_ok, opA, opB, oa, ob);
-    const int n = Ka * Nb;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(min((n + 255) / 256, 2048)), dim3(256), 0, s,
-                       (const float*)slab, out, n, splits, (size_t)Ka * Nb);
-    if (dbias)
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((Nb + 255) / 256), dim3(256), 0, s,
-                           (const float*)bias_slab, dbias, Nb, splits, (size_t)Nb);
+    launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
+    if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -23,6 +23,19 @@ void ishara_set_error(const char* fmt, ...) {
 extern "C" const char* ishara_last_error(void) { return g_err; }
 
 #define CK(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
+// profiled launch: key = kernel family, by = algorithmic bytes, fl = flops of this launch
+#define CKP(m, key, by, fl, expr)                                                          \
+    do {                                                                                   \
+        ProfRec* _pr = nullptr;                                                            \
+        if ((m)->prof.on) {                                                                \
+            (m)->prof.recs.push_back(ProfRec{key, (m)->prof.get(), (m)->prof.get(), (double)(by), (double)(fl)}); \
+            _pr = &(m)->prof.recs.back();                                                  \
+            (void)hipEventRecord(_pr->e0, (m)->s);                                         \
+        }                                                                                  \
+        int _r = (expr);                                                                   \
+        if (_pr) (void)hipEventRecord(_pr->e1, (m)->s);                                    \
+        if (_r != 0) return _r;                                                            \
+    } while (0)
 
 static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -95,8 +108,23 @@ struct Layer {            // one entry of the sequential graph
 struct SqzBlock { FFN ffn1; MHSA mha; SqzConv conv; FFN ffn2; };
 struct ConfBlock { FFN ffn1; MHSA mha; ConfConv conv; FFN ffn2; };
 
+// HIP-event profiler: when enabled every kernel launch site records a (start, stop) event pair
+// on the launch stream plus the algorithmic bytes / flops of that launch (bench.py roofline).
+struct ProfRec { const char* key; hipEvent_t e0, e1; double bytes, flops; };
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+        return pool[used++];
+    }
+};
+
 struct ishara_model {
     ishara_config cfg;
+    Profiler prof;
     int dt;                       // activation / MFMA dtype
     int d, T, F, C, H, dh, dtop, Bmax, L;
     std::vector<ParamEntry> entries;
@@ -425,13 +453,19 @@ extern "C" int ishara_sync_weights(ishara_model* m, ishara_stream st) {
 // ------------------------------------------------------------------ GEMM wrappers
 static int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea) {
     if (w.b >= 0) ea.bias = m->P(w.b);
-    return launch_gemm_nt(dtA, m->dt, dtC, aop, A, m->ws + w.wt, Cc, M, w.N, w.K, w.ldt, oa, ea, m->s);
+    const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtC) * (1 + (ea.resid ? 1 : 0) + (ea.pre_out ? 1 : 0)) + (double)w.K * w.N * dt_size(m->dt);
+    CKP(m, "gemm_nt", by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, dtC, aop, A, m->ws + w.wt, Cc, M, w.N, w.K, w.ldt, oa, ea, m->s));
+    return 0;
 }
 static int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea) {
-    return launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s);
+    const double by = (double)M * w.N * dt_size(dtA) + (double)M * w.K * dt_size(m->dt) * (1 + (ea.resid ? 1 : 0) + (ea.aux ? 1 : 0)) + (double)w.K * w.N * dt_size(m->dt);
+    CKP(m, "gemm_nt", by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
+    return 0;
 }
 static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M) {
-    return launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s);
+    const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
+    CKP(m, "gemm_tn", by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s));
+    return 0;
 }
 
 struct Run { int B, M, training; uint32_t seed; };
@@ -444,11 +478,11 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     CK(gemm_fwd(m, cb.W1, x, dt, m->W(cb.z1), dt, r.M, OP_NONE, no, e1));
     HIP_CHECK_RET(hipMemsetAsync(m->W(cb.ssum), 0, (size_t)B * c * 4, m->s));
     HIP_CHECK_RET(hipMemsetAsync(m->W(cb.ssq), 0, (size_t)B * c * 4, m->s));
-    CK(launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), B, T, c, cb.k, cb.k - 1, m->s));
-    CK(launch_bn_finalize(m->Wf(cb.ssum), m->Wf(cb.ssq), B, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), B, T, c, cb.k, cb.k - 1, m->s));
+    CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(cb.ssum), m->Wf(cb.ssq), B, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
                           m->P(cb.bn.mm), m->P(cb.bn.mv), r.training, m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.bsh), c, m->s));
-    CK(launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s));
-    CK(launch_sample_affine(dt, m->W(cb.h2), m->Wf(cb.P), m->Wf(cb.Q), nullptr, m->W(cb.h4), B, T, c, m->s));
+    CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s));
+    CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, m->W(cb.h2), m->Wf(cb.P), m->Wf(cb.Q), nullptr, m->W(cb.h4), B, T, c, m->s));
     const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
     EpiArgs e2; e2.resid = x;
     if (ds.thr) {
@@ -462,7 +496,7 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
 static int ffn_fwd(ishara_model* m, FFN& f, const Run& r, const void* x) {
     const int dt = m->dt;
     OpArgs no;
-    CK(launch_layernorm_fwd(dt, x, m->P(f.ln.gamma), m->P(f.ln.beta), f.eps, m->W(f.xn), m->Wf(f.mean), m->Wf(f.rstd), r.M, m->d, m->s));
+    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, x, m->P(f.ln.gamma), m->P(f.ln.beta), f.eps, m->W(f.xn), m->Wf(f.mean), m->Wf(f.rstd), r.M, m->d, m->s));
     EpiArgs ea; ea.pre_out = m->W(f.za); ea.act = ACT_SWISH; ea.drop = dspec(r, f.site_in, m->cfg.dropout_rate);
     CK(gemm_fwd(m, f.Wa, m->W(f.xn), dt, m->W(f.u), dt, r.M, OP_NONE, no, ea));
     EpiArgs eb; eb.resid = x;
@@ -474,11 +508,11 @@ static int ffn_fwd(ishara_model* m, FFN& f, const Run& r, const void* x) {
 static int mhsa_fwd(ishara_model* m, MHSA& a, const Run& r, const void* x) {
     const int dt = m->dt;
     OpArgs no;
-    CK(launch_layernorm_fwd(dt, x, m->P(a.ln.gamma), m->P(a.ln.beta), a.eps, m->W(a.xn), m->Wf(a.mean), m->Wf(a.rstd), r.M, m->d, m->s));
+    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, x, m->P(a.ln.gamma), m->P(a.ln.beta), a.eps, m->W(a.xn), m->Wf(a.mean), m->Wf(a.rstd), r.M, m->d, m->s));
     EpiArgs eq; eq.mode = EPI_QKV; eq.q = m->W(a.q); eq.k = m->W(a.k); eq.vt = m->W(a.vt); eq.H = m->H; eq.dh = m->dh; eq.T = m->T; eq.head_major = 1;
     CK(gemm_fwd(m, a.Wqkv, m->W(a.xn), dt, nullptr, dt, r.M, OP_NONE, no, eq));
     const float scale = 1.0f / sqrtf((float)m->d);     // self.scale = dim ** -0.5 (c5:95)
-    CK(launch_attn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->Wf(a.lse), r.B, m->H, m->T, m->dh, scale,
+    CKP(m, "attn_fwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 4.0 * r.B * m->H * (double)m->T * m->T * m->dh, launch_attn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->Wf(a.lse), r.B, m->H, m->T, m->dh, scale,
                        dspec(r, a.site_attn, a.rate), m->cfg.attn_impl, m->s));
     EpiArgs ep; ep.resid = x;
     if (a.has_out_drop) ep.drop = dspec(r, a.site_out, m->cfg.dropout_rate);
@@ -489,13 +523,13 @@ static int mhsa_fwd(ishara_model* m, MHSA& a, const Run& r, const void* x) {
 static int sqzconv_fwd(ishara_model* m, SqzConv& c, const Run& r, const void* x) {
     const int dt = m->dt, d = m->d, de = c.Wc1.N, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
-    CK(launch_layernorm_fwd(dt, x, m->P(c.ln.gamma), m->P(c.ln.beta), 1e-6f, m->W(c.xn), m->Wf(c.mean), m->Wf(c.rstd), r.M, d, m->s));
+    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, x, m->P(c.ln.gamma), m->P(c.ln.beta), 1e-6f, m->W(c.xn), m->Wf(c.mean), m->Wf(c.rstd), r.M, d, m->s));
     CK(gemm_fwd(m, c.Wc1, m->W(c.xn), dt, m->W(c.zc), dt, r.M, OP_NONE, no, e0));
-    CK(launch_dwconv_fwd(dt, DWIN_SWISH, m->W(c.zc), m->P(c.dw), nullptr, m->W(c.zd), nullptr, nullptr, B, T, de, c.k, c.k - 1, m->s));
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(c.zc), m->P(c.dw), nullptr, m->W(c.zd), nullptr, nullptr, B, T, de, c.k, c.k - 1, m->s));
     CK(gemm_fwd(m, c.Wc3, m->W(c.zd), dt, m->W(c.u3), dt, r.M, OP_SWISH, no, e0));
-    CK(launch_sample_reduce(dt, m->W(c.u3), nullptr, nullptr, nullptr, m->Wf(c.gap), nullptr, B, T, d, m->s));
-    CK(launch_se_fwd(m->Wf(c.gap), 1.f / T, m->P(c.seW1), m->P(c.seb1), m->P(c.seW2), m->P(c.seb2), m->Wf(c.hid), m->Wf(c.se), B, d, c.R, m->s));
-    CK(launch_sample_affine(dt, m->W(c.u3), m->Wf(c.se), nullptr, x, m->W(c.out), B, T, d, m->s));
+    CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(c.u3), nullptr, nullptr, nullptr, m->Wf(c.gap), nullptr, B, T, d, m->s));
+    CKP(m, "se_fwd", 0, 0, launch_se_fwd(m->Wf(c.gap), 1.f / T, m->P(c.seW1), m->P(c.seb1), m->P(c.seW2), m->P(c.seb2), m->Wf(c.hid), m->Wf(c.se), B, d, c.R, m->s));
+    CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, m->W(c.u3), m->Wf(c.se), nullptr, x, m->W(c.out), B, T, d, m->s));
     return 0;
 }
 
@@ -505,13 +539,13 @@ static int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* 
     CK(gemm_fwd(m, c.Wp1, x, dt, m->W(c.g), dt, r.M, OP_NONE, no, e0));
     HIP_CHECK_RET(hipMemsetAsync(m->W(c.ssum), 0, (size_t)B * d * 4, m->s));
     HIP_CHECK_RET(hipMemsetAsync(m->W(c.ssq), 0, (size_t)B * d * 4, m->s));
-    CK(launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), B, T, d, c.k, (c.k - 1) / 2, m->s));
-    CK(launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), 1e-3f, 0.99f,
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), B, T, d, c.k, (c.k - 1) / 2, m->s));
+    CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), 1e-3f, 0.99f,
                           m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s));
     OpArgs oa; oa.c1 = m->Wf(c.a); oa.c0 = m->Wf(c.bsh);
     EpiArgs e2; e2.resid = x;
     CK(gemm_fwd(m, c.Wp2, m->W(c.v), dt, m->W(c.r), dt, r.M, OP_COLAFFINE, oa, e2));
-    CK(launch_layernorm_fwd(dt, m->W(c.r), m->P(c.ln.gamma), m->P(c.ln.beta), 1e-3f, m->W(c.out), m->Wf(c.lnmean), m->Wf(c.lnrstd), r.M, d, m->s));
+    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, m->W(c.r), m->P(c.ln.gamma), m->P(c.ln.beta), 1e-3f, m->W(c.out), m->Wf(c.lnmean), m->Wf(c.lnrstd), r.M, d, m->s));
     return 0;
 }
 
@@ -525,10 +559,10 @@ extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float*
     // ---- stem: Dense(no bias) + PE, BatchNorm(momentum .95)  (c7:13-17)
     EpiArgs es; es.addtab = m->Wf(m->pe); es.tab_period = T;
     CK(gemm_fwd(m, m->stemW, x, DT_F32, m->W(m->stem_h0), dt, r.M, OP_NONE, no, es));
-    CK(launch_sample_reduce(dt, m->W(m->stem_h0), m->W(m->stem_h0), nullptr, nullptr, m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, T, d, m->s));
-    CK(launch_bn_finalize(m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, (float)B * T, m->P(m->stem_bn.gamma), m->P(m->stem_bn.beta), 1e-3f, 0.95f,
+    CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->stem_h0), m->W(m->stem_h0), nullptr, nullptr, m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, T, d, m->s));
+    CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, (float)B * T, m->P(m->stem_bn.gamma), m->P(m->stem_bn.beta), 1e-3f, 0.95f,
                           m->P(m->stem_bn.mm), m->P(m->stem_bn.mv), training, m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->stem_a), m->Wf(m->stem_bsh), d, m->s));
-    CK(launch_col_affine(dt, m->W(m->stem_h0), m->Wf(m->stem_a), m->Wf(m->stem_bsh), m->W(m->stem_out), r.M, d, m->s));
+    CKP(m, "col_affine", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_col_affine(dt, m->W(m->stem_h0), m->Wf(m->stem_a), m->Wf(m->stem_bsh), m->W(m->stem_out), r.M, d, m->s));
     const void* h = m->W(m->stem_out);
     for (const Layer& L : m->layers) {
         if (L.kind == Layer::CONV) { ConvBlock& cb = m->convs[L.idx]; CK(conv_fwd(m, cb, r, h)); h = m->W(cb.out); }
@@ -565,11 +599,11 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
     CK(gemm_dgrad(m, cb.W2, g, dt, m->W(m->t1), r.M, OP_NONE, no, e1));                        // dh4
     OpArgs ob; int bop = OP_NONE; if (ds.thr) { ob.rs = m->Wf(cb.rs); ob.T = T; bop = OP_ROWSCALE; }
     CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, g, dt, bop, ob, r.M));
-    CK(launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
-    CK(launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
+    CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
+    CKP(m, "eca_bn_bwd_finalize", 0, 0, launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
                                   m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), B, T, c, m->s));
-    CK(launch_bn_bwd_apply(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.sg), m->Wf(m->E), 1, m->Wf(m->Fc), m->W(m->t1), B, T, c, m->s));
-    CK(launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, B, T, c, cb.k, cb.k - 1, m->s));
+    CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.sg), m->Wf(m->E), 1, m->Wf(m->Fc), m->W(m->t1), B, T, c, m->s));
+    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, B, T, c, cb.k, cb.k - 1, m->s));
     EpiArgs e2; e2.resid = g;
     CK(gemm_dgrad(m, cb.W1, m->W(m->t2), dt, gn, r.M, OP_NONE, no, e2));
     CK(gemm_wgrad(m, cb.W1, x, dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
@@ -587,7 +621,7 @@ static int ffn_bwd(ishara_model* m, FFN& f, const Run& r, const void* x, const v
     EpiArgs e0;
     CK(gemm_dgrad(m, f.Wa, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));              // dxn
     CK(gemm_wgrad(m, f.Wa, m->W(f.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CK(launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(f.mean), m->Wf(f.rstd), m->P(f.ln.gamma), g, gn, m->G(f.ln.gamma), m->G(f.ln.beta), r.M, m->d, m->s));
+    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(f.mean), m->Wf(f.rstd), m->P(f.ln.gamma), g, gn, m->G(f.ln.gamma), m->G(f.ln.beta), r.M, m->d, m->s));
     return 0;
 }
 
@@ -599,42 +633,42 @@ static int mhsa_bwd(ishara_model* m, MHSA& a, const Run& r, const void* x, const
     CK(gemm_dgrad(m, a.Wp, g, dt, m->W(m->t1), r.M, oop, oo, e0));                              // do
     CK(gemm_wgrad(m, a.Wp, m->W(a.o), dt, OP_NONE, no, g, dt, oop, oo, r.M));
     const float scale = 1.0f / sqrtf((float)m->d);
-    CK(launch_attn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta), m->W(m->t2),
+    CKP(m, "attn_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 10.0 * r.B * m->H * (double)m->T * m->T * m->dh, launch_attn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta), m->W(m->t2),
                        r.B, m->H, m->T, m->dh, scale, dspec(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, m->s));
     CK(gemm_dgrad(m, a.Wqkv, m->W(m->t2), dt, m->W(m->t1), r.M, OP_NONE, no, e0));            // dxn
     CK(gemm_wgrad(m, a.Wqkv, m->W(a.xn), dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
-    CK(launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), r.M, m->d, m->s));
+    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), r.M, m->d, m->s));
     return 0;
 }
 
 static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt, d = m->d, de = c.Wc1.N, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
-    CK(launch_sample_reduce(dt, g, m->W(c.u3), nullptr, nullptr, m->Wf(m->S1), m->Wf(m->dse), B, T, d, m->s));   // dse = sum_t g*u3
-    CK(launch_se_bwd(m->Wf(m->dse), m->Wf(c.gap), 1.f / T, m->P(c.seW1), m->P(c.seW2), m->Wf(c.hid), m->Wf(c.se),
+    CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, g, m->W(c.u3), nullptr, nullptr, m->Wf(m->S1), m->Wf(m->dse), B, T, d, m->s));   // dse = sum_t g*u3
+    CKP(m, "se_bwd", 0, 0, launch_se_bwd(m->Wf(m->dse), m->Wf(c.gap), 1.f / T, m->P(c.seW1), m->P(c.seW2), m->Wf(c.hid), m->Wf(c.se),
                      m->G(c.seW1), m->G(c.seb1), m->G(c.seW2), m->G(c.seb2), m->Wf(m->dgapT), B, d, c.R, m->s));
-    CK(launch_sample_affine(dt, g, m->Wf(c.se), m->Wf(m->dgapT), nullptr, m->W(m->t1), B, T, d, m->s));           // du3
+    CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, g, m->Wf(c.se), m->Wf(m->dgapT), nullptr, m->W(m->t1), B, T, d, m->s));           // du3
     EpiArgs e1; e1.dact = DACT_SWISH; e1.aux = m->W(c.zd);
     CK(gemm_dgrad(m, c.Wc3, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e1));                                // dzd
     CK(gemm_wgrad(m, c.Wc3, m->W(c.zd), dt, OP_SWISH, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CK(launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, B, T, de, c.k, c.k - 1, m->s));   // dzc
+    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, B, T, de, c.k, c.k - 1, m->s));   // dzc
     CK(gemm_dgrad(m, c.Wc1, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // dxn
     CK(gemm_wgrad(m, c.Wc1, m->W(c.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CK(launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(c.mean), m->Wf(c.rstd), m->P(c.ln.gamma), g, gn, m->G(c.ln.gamma), m->G(c.ln.beta), r.M, d, m->s));
+    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(c.mean), m->Wf(c.rstd), m->P(c.ln.gamma), g, gn, m->G(c.ln.gamma), m->G(c.ln.beta), r.M, d, m->s));
     return 0;
 }
 
 static int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
-    CK(launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), r.M, d, m->s));   // dr
+    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), r.M, d, m->s));   // dr
     CK(gemm_dgrad(m, c.Wp2, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // d bn(v)
     OpArgs oa; oa.c1 = m->Wf(c.a); oa.c0 = m->Wf(c.bsh);
     CK(gemm_wgrad(m, c.Wp2, m->W(c.v), dt, OP_COLAFFINE, oa, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CK(launch_sample_reduce(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
-    CK(launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(c.bn.gamma), m->G(c.bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
-    CK(launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv
-    CK(launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
+    CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
+    CKP(m, "bn_bwd_finalize", 0, 0, launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(c.bn.gamma), m->G(c.bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
+    CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv
+    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
     EpiArgs e2; e2.resid = m->W(m->t1);
     CK(gemm_dgrad(m, c.Wp1, m->W(m->t3), dt, gn, r.M, OP_NONE, no, e2));
     CK(gemm_wgrad(m, c.Wp1, x, dt, OP_NONE, no, m->W(m->t3), dt, OP_NONE, no, r.M));
@@ -650,8 +684,8 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
     OpArgs no; EpiArgs e0;
     float* nl = nll ? nll : m->Wf(m->nllb);
     HIP_CHECK_RET(hipMemsetAsync(m->grads, 0, (size_t)m->n_train * sizeof(float), m->s));
-    CK(launch_ctc(logits, labels, B, T, m->C, m->L, m->C - 1, nl, m->Wf(m->dlogits), loss_scale / (float)B, m->Wf(m->ctcws), m->s));
-    if (loss) CK(launch_mean(nl, loss, B, 1.f / (float)B, m->s));
+    CKP(m, "ctc", 2.0 * r.M * m->C * 4, 0, launch_ctc(logits, labels, B, T, m->C, m->L, m->C - 1, nl, m->Wf(m->dlogits), loss_scale / (float)B, m->Wf(m->ctcws), m->s));
+    if (loss) CKP(m, "mean", 0, 0, launch_mean(nl, loss, B, 1.f / (float)B, m->s));
     // ---- head
     // input of the head = output of the last layer
     const void* hin = m->W(m->stem_out);
@@ -691,9 +725,9 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
 #undef STEP
     }
     // ---- stem
-    CK(launch_sample_reduce(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
-    CK(launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(m->stem_bn.gamma), m->G(m->stem_bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
-    CK(launch_bn_bwd_apply(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->stem_a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t1), B, T, d, m->s));
+    CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
+    CKP(m, "bn_bwd_finalize", 0, 0, launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(m->stem_bn.gamma), m->G(m->stem_bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
+    CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->stem_a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t1), B, T, d, m->s));
     CK(gemm_wgrad(m, m->stemW, m->last_x, DT_F32, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
     return 0;
 }
@@ -714,11 +748,45 @@ extern "C" int ishara_optimizer_step(ishara_model* m, float lr, float weight_dec
     a.r_t = a.rect ? (float)sqrt(fmax((sma_t - 4.0) / (sma_inf - 4.0) * (sma_t - 2.0) / (sma_inf - 2.0) * sma_inf / sma_t, 0.0)) : 0.f;
     a.sync = (m->opt_iter % 5 == 0) ? 1 : 0;   // Lookahead(sync_period=5, slow_step_size=0.5) (c7:69)
     a.slow_step = 0.5f;
-    CK(launch_radam_lookahead(m->params, m->grads, m->om, m->ov, m->oslow, m->n_train, a, s));
-    return ishara_sync_weights(m, st);
+    m->s = s;
+    CKP(m, "radam_lookahead", 28.0 * m->n_train, 0, launch_radam_lookahead(m->params, m->grads, m->om, m->ov, m->oslow, m->n_train, a, s));
+    CKP(m, "weight_shadows", 0, 0, ishara_sync_weights(m, st));
+    return 0;
 }
 extern "C" int32_t ishara_optimizer_iterations(const ishara_model* m) { return m->opt_iter; }
 extern "C" int ishara_optimizer_set_iterations(ishara_model* m, int32_t it) { m->opt_iter = it; return 0; }
+
+// ------------------------------------------------------------------ profiler API
+extern "C" int ishara_profile_enable(ishara_model* m, int32_t on) {
+    m->prof.on = on != 0;
+    m->prof.recs.clear();
+    m->prof.used = 0;
+    return 0;
+}
+// one text line per kernel family: "key count total_ms bytes flops\n"; returns bytes written (or <0)
+extern "C" int ishara_profile_report(ishara_model* m, char* buf, int32_t cap) {
+    struct Agg { int n = 0; double ms = 0, by = 0, fl = 0; };
+    std::map<std::string, Agg> agg;
+    std::vector<std::string> order;
+    for (auto& r : m->prof.recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) { ishara_set_error("profile: event sync failed"); return -2; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (!agg.count(r.key)) order.push_back(r.key);
+        Agg& a = agg[r.key];
+        a.n++; a.ms += ms; a.by += r.bytes; a.fl += r.flops;
+    }
+    int pos = 0;
+    for (auto& k : order) {
+        const Agg& a = agg[k];
+        const int w = snprintf(buf + pos, cap > pos ? cap - pos : 0, "%s %d %.6f %.0f %.0f\n", k.c_str(), a.n, a.ms, a.by, a.fl);
+        if (w < 0 || pos + w >= cap) { ishara_set_error("profile: buffer too small"); return -1; }
+        pos += w;
+    }
+    m->prof.recs.clear();
+    m->prof.used = 0;
+    return pos;
+}
 
 // ------------------------------------------------------------------ stand-alone entry points
 extern "C" int ishara_greedy_decode(const float* logits, int32_t B, int32_t T, int32_t C, int32_t blank, int32_t* out_idx, int32_t* out_len, ishara_stream s) {
@@ -735,6 +803,9 @@ extern "C" int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, i
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, out, rows, cols, d);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+extern int g_force_regstage;
+extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = on; return 0; }
 
 // ---- operator tests: dense
 static void op_shadow_layout(int dt, int K, int N, size_t& wt, int& ldt, size_t& wn, int& ldn, size_t& slab, size_t& total, int M) {

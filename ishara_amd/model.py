@@ -325,6 +325,24 @@ class Model:
         for cb in callbacks: getattr(cb, "on_train_end", lambda logs=None: None)()
         return hist
 
+    def profile_step(self, x, y, seed: Optional[int] = None) -> Dict[str, dict]:
+        """One training step with every kernel launch bracketed by HIP events on the launch stream.
+        Returns {kernel family: {launches, ms, bytes (algorithmic), flops}}."""
+        _lib.check(self._lib.ishara_profile_enable(self._h, 1))
+        try:
+            self.train_on_batch(x, y, seed=seed)
+            buf = C.create_string_buffer(1 << 16)
+            n = self._lib.ishara_profile_report(self._h, buf, len(buf))
+            if n < 0:
+                _lib.check(n, "ishara_profile_report")
+        finally:
+            self._lib.ishara_profile_enable(self._h, 0)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            k, cnt, ms, by, fl = line.split()
+            out[k] = dict(launches=int(cnt), ms=float(ms), bytes=float(by), flops=float(fl))
+        return out
+
     def ctc_loss(self, y, logits) -> torch.Tensor:
         """CTCLoss(labels, logits) (c6:1-13) on the GPU; returns per-sample nll [B]."""
         logits = logits.to(self.device, torch.float32).contiguous()

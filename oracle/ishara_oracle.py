@@ -528,7 +528,7 @@ def loss_and_grads(params: Dict[str, np.ndarray], x: np.ndarray, y: np.ndarray, 
     loss = ctc_loss(torch.from_numpy(y).long(), logits)
     loss.backward()
     grads = {k: (v.grad.detach().numpy() if v.grad is not None else None) for k, v in P.items() if v.requires_grad}
-    return float(loss), logits.detach().numpy(), grads, {k: v.numpy() for k, v in new_stats.items()}
+    return float(loss.detach()), logits.detach().numpy(), grads, {k: v.numpy() for k, v in new_stats.items()}
 
 
 def synthetic_batch(cfg: Config, B: int, seed: int = 1):

@@ -87,14 +87,19 @@ def test_train_step_parity(name, dtype, dropout):
         assert lerr <= 0.15, f"logits max-abs-err {lerr:.3e}"
         assert abs(loss - ref_loss) <= 2e-2 * abs(ref_loss), (loss, ref_loss)
     bad = []
+    gscale = max(float(np.abs(v).max()) for v in ref_grads.values())
     for n, rg in ref_grads.items():
         gg = grads[n]
-        if dtype == "f32":
-            e = _relerr(gg, rg)
-            if e > 1e-3 and np.abs(gg - rg).max() > 1e-6: bad.append((n, e))
+        if np.abs(rg).max() < 1e-6 * gscale:
+            # analytically-zero gradient (a conv bias in front of BatchNorm): only rounding noise is left
+            if np.abs(gg).max() > (1e-3 if dtype == "f32" else 3e-2) * gscale: bad.append((n, float(np.abs(gg).max() / gscale)))
+        elif dtype == "f32":
+            e = float(np.abs(gg - rg).max() / np.abs(rg).max())
+            if e > 1e-3: bad.append((n, e))
         else:
-            e = float(np.linalg.norm(gg - rg) / (np.linalg.norm(rg) + 1e-12))
-            if e > 0.12 and np.linalg.norm(rg) > 1e-4: bad.append((n, e))
+            e = float(np.linalg.norm(gg - rg) / np.linalg.norm(rg))
+            lim = 0.2 if rg.size <= 8 else 0.12      # 5-tap ECA kernels: difference of bf16-rounded sums
+            if e > lim: bad.append((n, e))
     assert not bad, f"gradient mismatch ({len(bad)}/{len(ref_grads)}): {sorted(bad, key=lambda t: -t[1])[:8]}"
     # BatchNorm moving statistics were updated in place by the training forward
     for n, rs in ref_stats.items():

@@ -34,9 +34,18 @@ def close(got, ref, name, rtol, atol):
     assert worst <= 0, f"{name}: max abs err {float(err.max()):.3e} (ref scale {float(ref.abs().max()):.3e}), exceeds tol by {worst:.3e}"
 
 
+@pytest.mark.parametrize("regstage", [0, 1])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0)])
-def test_dense_fwd_bwd(lib, dt, M, K, N, act):
+@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0), (3000, 768, 256, 0)])
+def test_dense_fwd_bwd(lib, dt, M, K, N, act, regstage):
+    lib.ishara_debug_force_regstage(regstage)
+    try:
+        _dense_fwd_bwd(lib, dt, M, K, N, act)
+    finally:
+        lib.ishara_debug_force_regstage(0)
+
+
+def _dense_fwd_bwd(lib, dt, M, K, N, act):
     code, tdt = DT[dt]
     g = torch.Generator().manual_seed(M + K + N)
     x = (torch.randn(M, K, generator=g)).to(tdt)
@@ -72,10 +81,10 @@ def test_layernorm(lib, dt, M, Cc):
     x = (torch.randn(M, Cc, generator=g) * 2 + 0.5).to(tdt)
     gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
     dy = torch.randn(M, Cc, generator=g).to(tdt)
-    xd, dyd = x.cuda(), dy.cuda()
+    xd, dyd, gd, btd = x.cuda(), dy.cuda(), dev(gamma), dev(beta)
     y = torch.empty_like(xd)
     mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
-    _lib.check(lib.ishara_op_layernorm_fwd(code, _lib.ptr(xd), _lib.ptr(dev(gamma)), _lib.ptr(dev(beta)), C.c_float(1e-6), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), M, Cc, stream()))
+    _lib.check(lib.ishara_op_layernorm_fwd(code, _lib.ptr(xd), _lib.ptr(gd), _lib.ptr(btd), C.c_float(1e-6), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), M, Cc, stream()))
     xr = x.double().requires_grad_(True)
     gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
     ref = F.layer_norm(xr, (Cc,), gr, br, 1e-6)
@@ -83,7 +92,7 @@ def test_layernorm(lib, dt, M, Cc):
     ref.backward(dy.double())
     dx = torch.empty_like(xd)
     dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
-    _lib.check(lib.ishara_op_layernorm_bwd(code, _lib.ptr(dyd), _lib.ptr(xd), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dev(gamma)), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, Cc, stream()))
+    _lib.check(lib.ishara_op_layernorm_bwd(code, _lib.ptr(dyd), _lib.ptr(xd), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, Cc, stream()))
     close(dx, xr.grad, "ln_dx", **TOL[dt])
     rtol = TOL[dt]["rtol"]
     close(dg, gr.grad, "ln_dgamma", rtol=rtol, atol=TOL[dt]["atol"] * M ** 0.5)
@@ -190,11 +199,11 @@ def test_ctc_and_decode(lib, B, T, L):
     lg = torch.from_numpy(logits).double().requires_grad_(True)
     ref = O.ctc_nll(torch.from_numpy(y), lg)
     ref.sum().backward()
-    ld = dev(logits)
+    ld, yd = dev(logits), dev(y, torch.int64)
     nll = torch.empty(B, device="cuda")
     dl = torch.empty(B, T, Cc, device="cuda")
     ws = torch.empty(int(lib.ishara_ctc_workspace_bytes(B, T, L)), dtype=torch.uint8, device="cuda")
-    _lib.check(lib.ishara_ctc_loss(_lib.ptr(ld), _lib.ptr(dev(y, torch.int64)), B, T, Cc, L, 59, _lib.ptr(nll), _lib.ptr(dl), C.c_float(1.0), _lib.ptr(ws), stream()))
+    _lib.check(lib.ishara_ctc_loss(_lib.ptr(ld), _lib.ptr(yd), B, T, Cc, L, 59, _lib.ptr(nll), _lib.ptr(dl), C.c_float(1.0), _lib.ptr(ws), stream()))
     close(nll, ref, "ctc_nll", rtol=1e-5, atol=1e-3)
     close(dl, lg.grad, "ctc_grad", rtol=1e-3, atol=2e-5)
     # greedy decode, bit exact (integer work), including ties and the dropped final run

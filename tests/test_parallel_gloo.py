@@ -1,0 +1,73 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of ishara_amd/parallel.py — batch
+sharding rank::world, one sum all-reduce of the flat gradient bucket with the 1/world mean folded
+into the loss scale, max-over-ranks timing.  The per-rank gradients come from the oracle (test
+infrastructure) so the exchange is checked against a single-process oracle that splits the batch
+into the same per-replica BatchNorm groups."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _flat(grads, names):
+    return np.concatenate([grads[n].reshape(-1) for n in names])
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from ishara_amd import parallel
+    from oracle import ishara_oracle as O
+    rk, w, _ = parallel.init_from_env("gloo")
+    assert (rk, w) == (rank, world) and parallel.world_size() == world and parallel.rank() == rank
+    cfg = O.Config(dim=32, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(24, 12), num_heads=4,
+                   kernel_sizes=(3,), num_conv_per_block=1, transformer_kernel_size=5, dropout_rate=0.0, head_dropout=0.0, conformer_attn_dropout=0.0)
+    W = O.init_params(cfg, 0)                      # identical replicas via the shared seed
+    x, y = O.synthetic_batch(cfg, 4, 1)            # global batch
+    xs, ys = parallel.shard_batch(x, y)
+    loss, _, grads, _ = O.loss_and_grads(W, xs, ys, cfg, training=True, seed=0)
+    names = [n for n, _, _, t in O.param_specs(cfg) if t]
+    bucket = torch.from_numpy(_flat(grads, names) * np.float32(1.0 / world))     # loss_scale = 1/world
+    parallel.allreduce_sum_(bucket)
+    tmax = parallel.reduce_max(float(rank + 1))
+    parallel.barrier()
+    if rank == 0:
+        np.save(out, np.concatenate([[loss, tmax], bucket.numpy()]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange(tmp_path):
+    from oracle import ishara_oracle as O
+    world, port = 2, 29511 + os.getpid() % 500
+    out = str(tmp_path / "r0.npy")
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    cfg = O.Config(dim=32, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(24, 12), num_heads=4,
+                   kernel_sizes=(3,), num_conv_per_block=1, transformer_kernel_size=5, dropout_rate=0.0, head_dropout=0.0, conformer_attn_dropout=0.0)
+    W = O.init_params(cfg, 0)
+    x, y = O.synthetic_batch(cfg, 4, 1)
+    names = [n for n, _, _, t in O.param_specs(cfg) if t]
+    ref = 0
+    for r in range(world):            # per-replica BatchNorm groups, mean of per-rank means
+        _, _, g, _ = O.loss_and_grads(W, x[r::world], y[r::world], cfg, training=True, seed=0)
+        ref = ref + _flat(g, names) / world
+    assert got[1] == 2.0                                   # max over ranks
+    assert np.allclose(got[2:], ref, rtol=1e-5, atol=1e-6)
+    # and it differs from one 4-sample BatchNorm group (documented consequence of per-replica BN)
+    _, _, gfull, _ = O.loss_and_grads(W, x, y, cfg, training=True, seed=0)
+    assert not np.allclose(got[2:], _flat(gfull, names), rtol=1e-3, atol=1e-5)
+
+
+def test_shard_batch_partition():
+    from ishara_amd import parallel
+    x = np.arange(16).reshape(8, 2)
+    parts = [parallel.shard_batch(x, x, r, 4)[0] for r in range(4)]
+    assert sorted(np.concatenate(parts)[:, 0].tolist()) == x[:, 0].tolist()
+    assert parallel.world_size() == 1 and parallel.rank() == 0
