@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const T* __restrict__ resid,
                                                             T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int M, int C) {
+                                                            float* __restrict__ partial, int M, int C) {
     constexpr int RPB = 256 / G;
     __shared__ float red[2][256][8];
     const int tid = threadIdx.x, gl = tid % G, gr = tid / G;
@@ -135,25 +135,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int e = 0; e < 8; ++e) {
             float a = 0.f, b = 0.f;
             for (int r = 0; r < RPB; ++r) { a += red[0][r * G + gl][e]; b += red[1][r * G + gl][e]; }
-            atomicAdd(dgamma + gl * 8 + e, a);
-            atomicAdd(dbeta + gl * 8 + e, b);
+            if (partial) {      // per-block partial rows [grid][2][C], summed by reduce_slabs (no same-address atomics)
+                partial[((size_t)blockIdx.x * 2) * C + gl * 8 + e] = a;
+                partial[((size_t)blockIdx.x * 2 + 1) * C + gl * 8 + e] = b;
+            } else {
+                atomicAdd(dgamma + gl * 8 + e, a);
+                atomicAdd(dbeta + gl * 8 + e, b);
+            }
         }
     }
 }
 
+void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s);
+
 int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd,
                          const float* gamma, const void* resid, void* dx, float* dgamma, float* dbeta,
-                         int M, int C, hipStream_t s) {
+                         float* scratch, int M, int C, hipStream_t s) {
     if (C % 8 != 0 || C > 512) { ishara_set_error("layernorm_bwd: C=%d unsupported", C); return -1; }
     const int G = next_pow2(C / 8);
     const int rpb = 256 / G;
     const int grid = max(1, min((M + 2 * rpb - 1) / (2 * rpb), 2048));
-#define LN_B(TT, GG) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, GG>), dim3(grid), dim3(256), 0, s, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)resid, (TT*)dx, dgamma, dbeta, M, C)
+#define LN_B(TT, GG) hipLaunchKernelGGL((layernorm_bwd_kernel<TT, GG>), dim3(grid), dim3(256), 0, s, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)resid, (TT*)dx, dgamma, dbeta, scratch, M, C)
 #define LN_BG(TT) switch (G) { case 1: LN_B(TT, 1); break; case 2: LN_B(TT, 2); break; case 4: LN_B(TT, 4); break; case 8: LN_B(TT, 8); break; \
                                case 16: LN_B(TT, 16); break; case 32: LN_B(TT, 32); break; default: LN_B(TT, 64); break; }
     if (dt == DT_BF16) { LN_BG(bf16) } else { LN_BG(float) }
+    if (scratch) {
+        launch_reduce_slabs(scratch, dgamma, C, grid, (size_t)2 * C, s);
+        launch_reduce_slabs(scratch + C, dbeta, C, grid, (size_t)2 * C, s);
+    }
     return LAUNCH_OK();
 }
+size_t layernorm_bwd_scratch_floats(int C) { return (size_t)2048 * 2 * C; }
 
 // =====================================================================================
 // Depthwise conv over time.  One workgroup = 64 output steps x 128 channels of one sample.

@@ -55,31 +55,29 @@ DEVI void apply_op(int op, float (&v)[N], int row, int col, const OpArgs& a) {
 
 // load N (4 or 8) consecutive elements of row `row` starting at column `col`, zero filled
 // outside [rows x cols]; vec_ok = row stride and base are 16-byte aligned.
-template <typename T, int N>
-__device__ __attribute__((noinline)) void load_row_chunk_slow(const T* __restrict__ p, int nvalid, float (&v)[N]) {
-#pragma unroll
-    for (int e = 0; e < N; ++e) v[e] = (e < nvalid) ? to_f(p[e]) : 0.f;
-}
+// load N (4 or 8) consecutive elements of row `row` starting at column `col`, zero filled outside
+// [rows x cols].  Row strides are multiples of 16 bytes (launchers enforce cols % 4 == 0 for f32,
+// cols % 8 == 0 for bf16), so a chunk is made of whole 16-byte pieces: no element-granular tail.
 template <typename T, int N>
 DEVI void load_row_chunk(const T* __restrict__ base, int ld, int rows, int cols, int row, int col,
-                         bool vec_ok, float (&v)[N]) {
-    if (row < rows && col < cols) {
-        const T* p = base + (size_t)row * ld + col;
-        if (vec_ok && col + N <= cols) {
+                         bool /*vec_ok*/, float (&v)[N]) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = 0.f;
+    if (row >= rows) return;
+    const T* p = base + (size_t)row * ld + col;
+    if constexpr (is_bf16_t<T>::value) {
+        if (col + N <= cols) {
             if constexpr (N == 8) load8(p, v);
-            else {
-                if constexpr (is_bf16_t<T>::value) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(p);
-                    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
-                    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
-                } else load4(p, v);
-            }
-        } else {
-            load_row_chunk_slow<T, N>(p, cols - col, v);
+            else load4g(p, v);
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[e] = 0.f;
+        for (int h = 0; h < N / 4; ++h) {
+            if (col + 4 * h + 4 <= cols) {
+                const float4 x = *reinterpret_cast<const float4*>(p + 4 * h);
+                v[4 * h] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
+            }
+        }
     }
 }
 
@@ -217,6 +215,108 @@ DEVI void epilogue_chunk(float (&v)[8], int m, int n, int nv, int N, const EpiAr
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Batched epilogue for one thread: a fixed 8-column chunk (n) of Q rows (m0r + q*mstep).
+// prefetch() issues every global read the epilogue needs (residual, act' operand, drop-path
+// scale, bias) as one batch BEFORE the accumulators are staged through LDS, so their latency
+// overlaps the staging instead of forming Q serial load->wait->store chains; finish() then
+// does the math and the 16-byte stores.  Partial chunks (N % 8) and the PE-table add take the
+// generic per-chunk path.
+// ---------------------------------------------------------------------------------
+template <typename TC, int Q>
+struct EpiRows {
+    float bias[8], res[Q][8], ax[Q][8], rs[Q];
+    int m[Q];
+    size_t off[Q];
+    int n, nv;
+    bool fast;
+
+    DEVI void prefetch(int m0r, int mstep, int n_, int M, int N, const EpiArgs& ea) {
+        n = n_;
+        nv = min(8, N - n);
+        fast = (nv == 8) && (ea.addtab == nullptr);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) m[q] = m0r + q * mstep;
+        if (!fast) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = ea.bias ? ea.bias[n + e] : 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) off[q] = (size_t)min(m[q], M - 1) * N + n;
+        if (ea.resid) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) load8(reinterpret_cast<const TC*>(ea.resid) + off[q], res[q]);
+        }
+        if (ea.dact != DACT_NONE) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) load8(reinterpret_cast<const TC*>(ea.aux) + off[q], ax[q]);
+        }
+        if (ea.rowscale) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) rs[q] = ea.rowscale[min(m[q], M - 1) / ea.T];
+        }
+    }
+
+    // stage: pointer to this thread's chunk of row q=0; sstep = floats between successive q rows
+    DEVI void finish(const float* stage, int sstep, int M, int N, const EpiArgs& ea, TC* __restrict__ C) {
+        if (n >= N) return;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float v[8];
+            const float4 x0 = *reinterpret_cast<const float4*>(stage + q * sstep);
+            const float4 x1 = *reinterpret_cast<const float4*>(stage + q * sstep + 4);
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+            if (!fast) {
+                if (m[q] < M) epilogue_chunk<TC>(v, m[q], n, nv, N, ea, C);
+                continue;
+            }
+            const bool ok = m[q] < M;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias[e];
+            if (ea.pre_out && ok) store8(reinterpret_cast<TC*>(ea.pre_out) + off[q], v);
+            if (ea.act == ACT_SWISH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+            } else if (ea.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (ea.drop.thr) {
+                const uint32_t rk = rng_row_key(ea.drop.key, (uint32_t)m[q]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rng_keep(rk, (uint32_t)(n + e), ea.drop.thr) ? v[e] * ea.drop.scale : 0.f;
+            }
+            if (ea.rowscale) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= rs[q];
+            }
+            if (ea.dact == DACT_SWISH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dswishf_(ax[q][e]);
+            } else if (ea.dact == DACT_POS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = ax[q][e] > 0.f ? v[e] : 0.f;
+            }
+            if (ea.resid) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += res[q][e];
+            }
+            if (!ok) continue;
+            if (ea.mode == EPI_STD) {
+                store8(C + off[q], v);
+            } else {
+                const int d = ea.H * ea.dh;
+                int h, part, i;
+                if (ea.head_major) { h = n / (3 * ea.dh); const int w = n - h * 3 * ea.dh; part = w / ea.dh; i = w - part * ea.dh; }
+                else { part = n / d; const int w = n - part * d; h = w / ea.dh; i = w - h * ea.dh; }
+                if (part < 2) {
+                    const int b = m[q] / ea.T, t = m[q] - b * ea.T;
+                    store8(reinterpret_cast<TC*>(part == 0 ? ea.q : ea.k) + ((size_t)(b * ea.H + h) * ea.T + t) * ea.dh + i, v);
+                }
+            }
+        }
+    }
+};
+
 // stage one K tile of A (transformed) and Bt into registers: 4 x 16-byte chunks each per thread
 template <typename TA, typename TM, int OP>
 DEVI void nt_gload(const TA* __restrict__ A, const TM* __restrict__ Bt, int M, int K, int ldb, bool a_vec_ok,
@@ -296,6 +396,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const TA* __restrict__ A, 
     constexpr int SLD = 132;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
+        EpiRows<TC, 4> er;       // thread -> columns (tid&15)*8.., rows (tid>>4) + 16q of this 64-row pass
+        er.prefetch(m0 + 64 * p + (tid >> 4), 16, n0 + (tid & 15) * 8, M, N, ea);
         if (wr == p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -306,18 +408,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const TA* __restrict__ A, 
                         stage[(16 * i + 4 * (lane >> 4) + r) * SLD + wc * 64 + 16 * j + (lane & 15)] = acc[i][j][r];
         }
         __syncthreads();
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int c = tid + 256 * qq, row = c >> 4, col = (c & 15) * 8;
-            const int m = m0 + 64 * p + row, n = n0 + col;
-            if (m < M && n < N) {
-                float v[8];
-                const float4 x0 = *reinterpret_cast<const float4*>(stage + row * SLD + col);
-                const float4 x1 = *reinterpret_cast<const float4*>(stage + row * SLD + col + 4);
-                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-                epilogue_chunk<TC>(v, m, n, min(8, N - n), N, ea, C);
-            }
-        }
+        er.finish(stage + (tid >> 4) * SLD + (tid & 15) * 8, 16 * SLD, M, N, ea, C);
         if (ea.mode == EPI_QKV) {   // V columns: write transposed vt[b,h,i,t], 8 consecutive t per store
             const int d = ea.H * ea.dh;
 #pragma unroll
@@ -448,20 +539,25 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const TM* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, 0, smem, wid, lane);
-    if (nk > 1) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, 1, smem + GL_STAGE, wid, lane);
+    const bool ld_on = !(ea.dbg & 4), mma_on = !(ea.dbg & 2);
+    if (ld_on) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, 0, smem, wid, lane);
+    if (nk > 1 && ld_on) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, 1, smem + GL_STAGE, wid, lane);
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // this wave's pieces of tile kt have landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                          // ... and everyone else's; tile kt-1 fully consumed
-        if (kt + 2 < nk) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, kt + 2, smem + ((kt + 2) % GL_NSTAGE) * GL_STAGE, wid, lane);
+        if (kt + 2 < nk && ld_on) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, kt + 2, smem + ((kt + 2) % GL_NSTAGE) * GL_STAGE, wid, lane);
         const char* st = smem + (kt % GL_NSTAGE) * GL_STAGE;
-        mma_tile_2x4<TM>(st, st + 8192, wr, wc, lane, acc);
+        if (mma_on) mma_tile_2x4<TM>(st, st + 8192, wr, wc, lane, acc);
     }
     __syncthreads();     // ring is free: reuse it as four wave-private fp32 stages
+    if (ea.dbg & 1) { if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][3][2]); return; }
 
     constexpr int SLD = 68;
     float* stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
+    const int mw = m0 + wr * 32, nw = n0 + wc * 64;
+    EpiRows<TC, 4> er;       // thread -> columns (lane&7)*8.., rows (lane>>3) + 8q
+    er.prefetch(mw + (lane >> 3), 8, nw + (lane & 7) * 8, M, N, ea);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -469,19 +565,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const TM* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 stage[(16 * i + 4 * (lane >> 4) + r) * SLD + 16 * j + (lane & 15)] = acc[i][j][r];
-    const int mw = m0 + wr * 32, nw = n0 + wc * 64;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-        const int c = lane + 64 * qq, row = c >> 3, col = (c & 7) * 8;
-        const int m = mw + row, n = nw + col;
-        if (m < M && n < N) {
-            float v[8];
-            const float4 x0 = *reinterpret_cast<const float4*>(stage + row * SLD + col);
-            const float4 x1 = *reinterpret_cast<const float4*>(stage + row * SLD + col + 4);
-            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-            epilogue_chunk<TC>(v, m, n, min(8, N - n), N, ea, C);
-        }
-    }
+    er.finish(stage + (lane >> 3) * SLD + (lane & 7) * 8, 8 * SLD, M, N, ea, C);
     if (ea.mode == EPI_QKV) {
         const int d = ea.H * ea.dh;
         const int n = nw + lane;
@@ -535,11 +619,15 @@ static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int 
     }
 }
 
-int g_force_regstage = 0;   // tests: force the register-staged kernels
+int g_force_regstage = 1;   // 1: register-staged 128x128 kernel (default, faster at K<=768); 0: LDS-DMA 64x128 kernel
+int g_dbg_tn = 0;           // ablation bits for the TN kernel: 1 skip MFMA, 2 skip LDS stores, 4 skip global loads
 
 int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
                    int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) { ishara_set_error("gemm_nt: bad shape %d %d %d", M, N, K); return -1; }
+    if ((dtA == DT_BF16 && K % 8 != 0) || (dtA == DT_F32 && K % 4 != 0) || ((uintptr_t)A) % 16 != 0) {
+        ishara_set_error("gemm_nt: A rows must be 16-byte aligned (K=%d)", K); return -1;
+    }
     if (ea.mode == EPI_QKV && (ea.T % 8 != 0 || N % 8 != 0 || ea.dh % 8 != 0)) {
         ishara_set_error("gemm_nt: QKV split needs T, dh multiples of 8 (T=%d dh=%d)", ea.T, ea.dh); return -1;
     }
@@ -633,7 +721,7 @@ template <typename TA, typename TB, typename TM>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const TA* __restrict__ A, const TB* __restrict__ B,
                                                       float* __restrict__ slab, float* __restrict__ bias_slab,
                                                       int M, int Ka, int Nb, int rows_per_split, int a_vec_ok, int b_vec_ok,
-                                                      int opA, int opB, OpArgs oa, OpArgs ob) {
+                                                      int opA, int opB, OpArgs oa, OpArgs ob, int dbg) {
     __shared__ __attribute__((aligned(16))) char smem[65536];
     constexpr int EPC = MmaCfg<TM>::EPC, MC = MmaCfg<TM>::BK;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1;
@@ -665,13 +753,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TA* __restrict__ A, 
     __syncthreads();
     for (int mc = 0; mc < nmc; ++mc) {
         const bool more = mc + 1 < nmc;
-        if (more) {
+        if (more && !(dbg & 4)) {
             stage_t_load<TA, TM>(A, Ka, m_end, Ka, m_beg + (mc + 1) * MC, k0, a_vec_ok != 0, opA, oa, tid, ra, nullptr);
             stage_t_load<TB, TM>(B, Nb, m_end, Nb, m_beg + (mc + 1) * MC, n0, b_vec_ok != 0, opB, ob, tid, rb, want_bias ? csum : nullptr);
         }
         const char* sa = smem + (mc & 1) * 32768;
-        mma_tile<TM, 1>(sa, sa + 16384, wr, wc, lane, acc);
-        if (more) {
+        if (!(dbg & 1)) mma_tile<TM, 1>(sa, sa + 16384, wr, wc, lane, acc);
+        if (more && !(dbg & 2)) {
             char* sn = smem + ((mc + 1) & 1) * 32768;
             stage_t_store<TM>(sn, tid, ra);
             stage_t_store<TM>(sn + 16384, tid, rb);
@@ -704,6 +792,134 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TA* __restrict__ A, 
 #pragma unroll
             for (int g = 0; g < GROUPS; ++g) sacc += red[g * 128 + tid];
             if (n0 + tid < Nb) bias_slab[(size_t)split * Nb + n0 + tid] = sacc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// TN kernel, bf16, LDS-DMA + hardware-transposed fragment reads (the common wgrad case: no
+// operand transform, M % 64 == 0, Ka % 128 == 0, Nb % 128 == 0).
+// Both operands are [m][feature] row-major in HBM and the MFMA reduction index is m, i.e. the
+// fragments are COLUMNS of the stored tiles.  Instead of transposing through registers, the
+// 64-row x 128-column tiles (256-byte rows) are copied as they are by global_load_lds_dwordx4
+// into a 4-deep LDS ring (three tiles in flight), and each fragment is fetched with two
+// ds_read_b64_tr_b16 (a 4-row x 16-column block delivered column-major).  The 32-byte column
+// blocks of a row are XOR-swizzled with f(row) = (row&3) | ((row>>3)&1)<<2 — applied on the
+// SOURCE address of the DMA and on the read — so the 8 rows a 32-lane half reads land in 8
+// different 32-byte bank groups (conflict-free).  The bias gradient (column sums of dY) is
+// accumulated from the B fragments already in registers.
+// ---------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+#define TR_STAGE 32768          // A 64 x 256 B + B 64 x 256 B
+#define TR_NSTAGE 4
+
+DEVI int tr_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+DEVI void tr_issue(const bf16* __restrict__ A, const bf16* __restrict__ B, int Ka, int Nb, int k0, int n0, int mrow0,
+                   char* stage, int wid, int lane) {
+    const int r = lane >> 4, sp = lane & 15;            // row within a 4-row piece, physical 16-byte slot
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                        // 16 pieces per operand; wave takes wid, wid+4, ...
+        const int pc = wid + 4 * u;
+        const int row = 4 * pc + r;
+        const int col = (((sp >> 1) ^ tr_f(row)) << 4) + ((sp & 1) << 3);     // logical column of physical slot sp
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)(mrow0 + row) * Ka + k0 + col),
+                                         (__attribute__((address_space(3))) void*)(stage + pc * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)(mrow0 + row) * Nb + n0 + col),
+                                         (__attribute__((address_space(3))) void*)(stage + 16384 + pc * 1024), 16, 0, 0);
+    }
+}
+
+// fragment of column block lb (16 columns), k-step s (32 rows): lane (g,q,p) addresses row 32s+8g+4h+q, 8 bytes at p
+DEVI bf16x8 tr_frag(const char* tile, int lb, int s, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int r0 = 32 * s + 8 * g + q, r1 = r0 + 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + r0 * 256 + ((lb ^ tr_f(r0)) << 5) + (pp << 3)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + r1 * 256 + ((lb ^ tr_f(r1)) << 5) + (pp << 3)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                         float* __restrict__ slab, float* __restrict__ bias_slab,
+                                                         int M, int Ka, int Nb, int rows_per_split) {
+    __shared__ __attribute__((aligned(16))) char smem[TR_NSTAGE * TR_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int nNt = Nb >> 7;
+    const int kt = blockIdx.x / nNt, nt = blockIdx.x % nNt;
+    const int k0 = kt << 7, n0 = nt << 7;
+    const int split = blockIdx.y;
+    const int m_beg = split * rows_per_split;
+    const int m_end = min(M, m_beg + rows_per_split);
+    const int nmc = (m_end - m_beg) >> 6;                 // whole 64-row tiles (launcher guarantees)
+    const bool want_bias = (bias_slab != nullptr) && (kt == 0) && (wr == 0);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int st = 0; st < TR_NSTAGE - 1; ++st)
+        if (st < nmc) tr_issue(A, B, Ka, Nb, k0, n0, m_beg + st * 64, smem + st * TR_STAGE, wid, lane);
+    for (int mc = 0; mc < nmc; ++mc) {
+        // 8 DMA per wave per tile; tiles mc+1, mc+2 may stay in flight
+        const int ahead = min(nmc - 1 - mc, TR_NSTAGE - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (mc + TR_NSTAGE - 1 < nmc)
+            tr_issue(A, B, Ka, Nb, k0, n0, m_beg + (mc + TR_NSTAGE - 1) * 64, smem + ((mc + TR_NSTAGE - 1) % TR_NSTAGE) * TR_STAGE, wid, lane);
+        const char* sa = smem + (mc % TR_NSTAGE) * TR_STAGE;
+        const char* sb = sa + 16384;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = tr_frag(sa, wr * 4 + i, s, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = tr_frag(sb, wc * 4 + j, s, lane);
+            if (want_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t += (float)b[j][e];
+                    csum[j] += t;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* out = slab + (size_t)split * Ka * Nb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = k0 + wr * 64 + 16 * i + 4 * (lane >> 4) + r;
+                const int nn = n0 + wc * 64 + 16 * j + (lane & 15);
+                out[(size_t)kk * Nb + nn] = acc[i][j][r];
+            }
+    if (want_bias) {   // lane (g, c) holds the sum over rows 8g..8g+7 (mod 32) of column 16j + c: fold the 4 row groups
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = csum[j];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (lane < 16) bias_slab[(size_t)split * Nb + n0 + wc * 64 + 16 * j + lane] = t;
         }
     }
 }
@@ -744,7 +960,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
-static void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s) {
+void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s) {
     const int gx = (n + 1023) / 1024;
     int gy = max(1, min(splits / 4, 2048 / max(gx, 1)));
     if (gy > 16) gy = 16;
@@ -765,7 +981,24 @@ static void tn_plan(int M, int Ka, int Nb, int dtM, int& splits, int& rows_per_s
 size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM) {
     int splits, rps;
     tn_plan(M, Ka, Nb, dtM, splits, rps);
+    if (splits < 256) splits = 256;        // the transposed-read kernel plans <= 256 splits
     return (size_t)splits * ((size_t)Ka * Nb + Nb);
+}
+
+int g_force_tn_regstage = 0;   // tests: force the register-transposing TN kernel
+
+static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s) {
+    const int tiles = (Ka / 128) * (Nb / 128);
+    int want = max(1, 256 / tiles);                       // one 128 KB-LDS workgroup per CU
+    const int maxs = max(1, M / 256);                     // at least 4 tiles per split
+    if (want > maxs) want = maxs;
+    const int rps = ((M + want - 1) / want + 63) / 64 * 64;
+    const int splits = (M + rps - 1) / rps;
+    float* bias_slab = dbias ? slab + (size_t)splits * Ka * Nb : nullptr;
+    hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles, splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps);
+    launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
+    if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <typename TA, typename TB, typename TM>
@@ -778,7 +1011,7 @@ static int run_tn(int opA, int opB, const void* A, const void* B, float* out, fl
     const int a_ok = (((size_t)Ka * sizeof(TA)) % 16 == 0) && (((uintptr_t)A) % 16 == 0);
     const int b_ok = (((size_t)Nb * sizeof(TB)) % 16 == 0) && (((uintptr_t)B) % 16 == 0);
     hipLaunchKernelGGL((gemm_tn_kernel<TA, TB, TM>), dim3(tiles, splits), dim3(256), 0, s,
-                       (const TA*)A, (const TB*)B, slab, bias_slab, M, Ka, Nb, rps, a_ok, b_ok, opA, opB, oa, ob);
+                       (const TA*)A, (const TB*)B, slab, bias_slab, M, Ka, Nb, rps, a_ok, b_ok, opA, opB, oa, ob, g_dbg_tn);
     launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
     if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -788,7 +1021,14 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
                    const OpArgs& oa, const OpArgs& ob, hipStream_t s) {
     if (M <= 0 || Ka <= 0 || Nb <= 0) { ishara_set_error("gemm_tn: bad shape"); return -1; }
+    if ((dtA == DT_BF16 && Ka % 8 != 0) || (dtA == DT_F32 && Ka % 4 != 0) || (dtB == DT_BF16 && Nb % 8 != 0) || (dtB == DT_F32 && Nb % 4 != 0) ||
+        ((uintptr_t)A) % 16 != 0 || ((uintptr_t)B) % 16 != 0) {
+        ishara_set_error("gemm_tn: operand rows must be 16-byte aligned (Ka=%d Nb=%d)", Ka, Nb); return -1;
+    }
     if (dtA == DT_F32 && dtB == DT_F32 && dtM == DT_F32) return run_tn<float, float, float>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
+    if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && opA == OP_NONE && opB == OP_NONE && M % 64 == 0 && Ka % 128 == 0 && Nb % 128 == 0 &&
+        M >= 256 && !g_force_tn_regstage)
+        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s);
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<bf16, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
     if (dtA == DT_F32 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<float, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
     if (dtA == DT_BF16 && dtB == DT_F32 && dtM == DT_BF16) return run_tn<bf16, float, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);

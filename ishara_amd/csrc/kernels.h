@@ -35,6 +35,7 @@ struct EpiArgs {
     int mode = EPI_STD;               // EPI_QKV: scatter to q,k [B,H,T,dh] and vt [B,H,dh,T]
     void* q = nullptr; void* k = nullptr; void* vt = nullptr;
     int H = 1, dh = 1;
+    int dbg = 0;                      // ablation bits (tools/gemm_ablate.py): 1 skip epilogue, 2 skip MFMA, 4 skip loads
     int head_major = 1;               // 1: cols = h*3dh + {q,k,v}*dh + i (TF path); 0: {q,k,v}*d + h*dh + i (torch twin)
 };
 
@@ -57,10 +58,12 @@ int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt,
 // ---- normalisation / conv / small ops (elementwise.hip) ---------------------------
 int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float* beta, float eps,
                          void* y, float* mean, float* rstd, int M, int C, hipStream_t s);
-// dx = LN'(dy) (+ resid) ; dgamma/dbeta accumulated atomically
+// dx = LN'(dy) (+ resid) ; dgamma/dbeta += column sums: through per-block partial rows in `scratch`
+// (layernorm_bwd_scratch_floats(C) floats) + a slab reduce, or same-address atomics if scratch == nullptr
+size_t layernorm_bwd_scratch_floats(int C);
 int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd,
                          const float* gamma, const void* resid, void* dx, float* dgamma, float* dbeta,
-                         int M, int C, hipStream_t s);
+                         float* scratch, int M, int C, hipStream_t s);
 
 enum : int { DWIN_NONE = 0, DWIN_SWISH = 1, DWIN_GLU = 2 };
 // y[b,t,c] = bias[c] + sum_j w[j,c] * in(x)[b, t - padl + j, c]; x has Cin = C (or 2C for GLU).

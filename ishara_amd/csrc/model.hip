@@ -367,6 +367,7 @@ static void plan_workspace(ishara_model* m) {
     m->dse = m->f32((size_t)B * d); m->dgapT = m->f32((size_t)B * d);
     size_t slabf = 0;
     for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > slabf) slabf = f; }
+    if (layernorm_bwd_scratch_floats(d) > slabf) slabf = layernorm_bwd_scratch_floats(d);
     m->slab = m->f32(slabf);
     m->ctcws = m->f32(ctc_workspace_floats(B, T, m->L));
     m->dlogits = m->f32(Mx * m->C);
@@ -383,7 +384,7 @@ extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     const int dh = c.dim / c.num_heads;
     if (dh != 8 && dh != 16 && dh != 32 && dh != 64) { ishara_set_error("head dim %d unsupported (8,16,32,64)", dh); return -1; }
     if (c.frames <= 0 || c.frames % 8 != 0 || c.frames > 512) { ishara_set_error("frames=%d unsupported (multiple of 8, <=512)", c.frames); return -1; }
-    if (c.features <= 0) { ishara_set_error("features must be > 0"); return -1; }
+    if (c.features <= 0 || c.features % 4 != 0) { ishara_set_error("features=%d unsupported (positive multiple of 4: 16-byte input rows)", c.features); return -1; }
     if (c.num_classes < 2 || c.num_classes > 64) { ishara_set_error("num_classes=%d unsupported (2..64)", c.num_classes); return -1; }
     if (c.num_kernel_sizes <= 0 && c.num_conv_per_block > 0) { ishara_set_error("kernel_sizes is empty"); return -1; }
     if (c.num_kernel_sizes > 8) { ishara_set_error("at most 8 kernel sizes"); return -1; }
@@ -621,7 +622,7 @@ static int ffn_bwd(ishara_model* m, FFN& f, const Run& r, const void* x, const v
     EpiArgs e0;
     CK(gemm_dgrad(m, f.Wa, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));              // dxn
     CK(gemm_wgrad(m, f.Wa, m->W(f.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(f.mean), m->Wf(f.rstd), m->P(f.ln.gamma), g, gn, m->G(f.ln.gamma), m->G(f.ln.beta), r.M, m->d, m->s));
+    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(f.mean), m->Wf(f.rstd), m->P(f.ln.gamma), g, gn, m->G(f.ln.gamma), m->G(f.ln.beta), m->Wf(m->slab), r.M, m->d, m->s));
     return 0;
 }
 
@@ -637,7 +638,7 @@ static int mhsa_bwd(ishara_model* m, MHSA& a, const Run& r, const void* x, const
                        r.B, m->H, m->T, m->dh, scale, dspec(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, m->s));
     CK(gemm_dgrad(m, a.Wqkv, m->W(m->t2), dt, m->W(m->t1), r.M, OP_NONE, no, e0));            // dxn
     CK(gemm_wgrad(m, a.Wqkv, m->W(a.xn), dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
-    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), r.M, m->d, m->s));
+    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), m->Wf(m->slab), r.M, m->d, m->s));
     return 0;
 }
 
@@ -654,14 +655,14 @@ static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x,
     CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, B, T, de, c.k, c.k - 1, m->s));   // dzc
     CK(gemm_dgrad(m, c.Wc1, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // dxn
     CK(gemm_wgrad(m, c.Wc1, m->W(c.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(c.mean), m->Wf(c.rstd), m->P(c.ln.gamma), g, gn, m->G(c.ln.gamma), m->G(c.ln.beta), r.M, d, m->s));
+    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(c.mean), m->Wf(c.rstd), m->P(c.ln.gamma), g, gn, m->G(c.ln.gamma), m->G(c.ln.beta), m->Wf(m->slab), r.M, d, m->s));
     return 0;
 }
 
 static int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
-    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), r.M, d, m->s));   // dr
+    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), m->Wf(m->slab), r.M, d, m->s));   // dr
     CK(gemm_dgrad(m, c.Wp2, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // d bn(v)
     OpArgs oa; oa.c1 = m->Wf(c.a); oa.c0 = m->Wf(c.bsh);
     CK(gemm_wgrad(m, c.Wp2, m->W(c.v), dt, OP_COLAFFINE, oa, m->W(m->t1), dt, OP_NONE, no, r.M));
@@ -804,8 +805,10 @@ extern "C" int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, i
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern int g_force_regstage;
-extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = on; return 0; }
+extern int g_force_regstage, g_dbg_tn, g_force_tn_regstage;
+static int g_dbg_epi = 0;
+// bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bits 4-7: NT ablation; bits 8-11: TN ablation
+extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = on & 1; g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 15; g_force_tn_regstage = (on >> 1) & 1; return 0; }
 
 // ---- operator tests: dense
 static void op_shadow_layout(int dt, int K, int N, size_t& wt, int& ldt, size_t& wn, int& ldn, size_t& slab, size_t& total, int M) {
@@ -829,7 +832,7 @@ extern "C" int ishara_op_dense_fwd(int32_t dt, const void* x, const float* Wm, c
     char* sc = (char*)scratch;
     HIP_CHECK_RET(hipMemsetAsync(sc, 0, slab, s));
     CK(launch_make_shadow(dt, Wm, K, N, sc + wt, ldt, sc + wn, ldn, s));
-    OpArgs no; EpiArgs ea; ea.bias = bias; ea.act = act;
+    OpArgs no; EpiArgs ea; ea.bias = bias; ea.act = act; ea.dbg = g_dbg_epi;
     return launch_gemm_nt(dt, dt, dt, OP_NONE, x, sc + wt, y, M, N, K, ldt, no, ea, s);
 }
 extern "C" int ishara_op_dense_bwd(int32_t dt, const void* x, const float* Wm, const void* dy, void* dx, float* dW, float* db,
@@ -848,7 +851,7 @@ extern "C" int ishara_op_layernorm_fwd(int32_t dt, const void* x, const float* g
     return launch_layernorm_fwd(dt, x, gamma, beta, eps, y, mean, rstd, M, C, (hipStream_t)s);
 }
 extern "C" int ishara_op_layernorm_bwd(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int32_t M, int32_t C, ishara_stream s) {
-    return launch_layernorm_bwd(dt, dy, x, mean, rstd, gamma, nullptr, dx, dgamma, dbeta, M, C, (hipStream_t)s);
+    return launch_layernorm_bwd(dt, dy, x, mean, rstd, gamma, nullptr, dx, dgamma, dbeta, nullptr, M, C, (hipStream_t)s);
 }
 extern "C" int ishara_op_dwconv_fwd(int32_t dt, int32_t inop, const void* x, const float* w, const float* bias, void* y, float* ssum, float* ssq,
                                     int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {

@@ -34,19 +34,21 @@ def close(got, ref, name, rtol, atol):
     assert worst <= 0, f"{name}: max abs err {float(err.max()):.3e} (ref scale {float(ref.abs().max()):.3e}), exceeds tol by {worst:.3e}"
 
 
-@pytest.mark.parametrize("regstage", [0, 1])
+@pytest.mark.parametrize("regstage", [0, 1, 3])   # bit0: register-staged NT (else LDS-DMA); bit1: register-transposing TN (else tr-read)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0), (3000, 768, 256, 0)])
+@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0), (3000, 768, 256, 0), (1024, 512, 256, 0), (4096, 128, 128, 0)])
 def test_dense_fwd_bwd(lib, dt, M, K, N, act, regstage):
     lib.ishara_debug_force_regstage(regstage)
     try:
         _dense_fwd_bwd(lib, dt, M, K, N, act)
     finally:
-        lib.ishara_debug_force_regstage(0)
+        lib.ishara_debug_force_regstage(1)
 
 
 def _dense_fwd_bwd(lib, dt, M, K, N, act):
     code, tdt = DT[dt]
+    if dt == "bf16" and K % 8:
+        pytest.skip("bf16 activations always have 16-byte rows (K % 8 == 0); the ragged-K stem input is f32")
     g = torch.Generator().manual_seed(M + K + N)
     x = (torch.randn(M, K, generator=g)).to(tdt)
     W = torch.randn(K, N, generator=g) / K ** 0.5

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Time one dense forward (x[M,K] @ W[K,N] + b) of the HIP library in isolation, with the
+ablation bits of EpiArgs.dbg (1 skip epilogue, 2 skip MFMA, 4 skip loads) and the
+register-staged vs LDS-DMA kernels, interleaved in one process (guide rule 24)."""
+import ctypes as C
+import sys
+import torch
+sys.path.insert(0, ".")
+from ishara_amd import _lib
+
+lib = _lib.load()
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+shapes = [(98304, 256, 512), (98304, 512, 256), (98304, 256, 768), (98304, 256, 256)]
+for (M, K, N) in shapes:
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    W = torch.randn(K, N, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
+    scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    res = {}
+    variants = {"glds": 0, "glds-noepi": 1 << 4, "glds-nomma": 2 << 4, "glds-noload": 4 << 4, "glds-onlyepi": 6 << 4,
+                "glds-onlyload": 3 << 4, "regstage": 1}
+    for rnd in range(3):
+        for name, flag in variants.items():
+            lib.ishara_debug_force_regstage(flag)
+            for _ in range(2):
+                lib.ishara_op_dense_fwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(y), M, K, N, 0, scp, st())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                lib.ishara_op_dense_fwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(y), M, K, N, 0, scp, st())
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(name, []).append(e0.elapsed_time(e1) / 10 * 1e3)
+    lib.ishara_debug_force_regstage(1)
+    gb = (M * K * 2 + M * N * 2) / 1e9
+    print(f"M{M} K{K} N{N}: " + "  ".join(f"{k}={min(v):.0f}us" for k, v in res.items()) + f"   [{gb / (min(res['glds']) * 1e-6) / 1e3:.2f} TB/s, includes shadow build+memset]")
+
+print("---- TN (wgrad): dW = x^T dy ; dx path excluded by timing dense_bwd minus its NT part is not possible, so time bwd as a whole")
+for (M, K, N) in [(98304, 256, 512), (98304, 512, 256)]:
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    dy = torch.randn(M, N, device="cuda").bfloat16()
+    W = torch.randn(K, N, device="cuda") / K ** 0.5
+    dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    dW = torch.zeros(K, N, device="cuda"); db = torch.zeros(N, device="cuda")
+    sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
+    scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    res = {}
+    for rnd in range(3):
+        for name, flag in {"full": 1, "tn-nomma": 1 | (1 << 8), "tn-nolds": 1 | (2 << 8), "tn-noload": 1 | (4 << 8), "tn-nothing": 1 | (7 << 8)}.items():
+            lib.ishara_debug_force_regstage(flag)
+            for _ in range(2):
+                lib.ishara_op_dense_bwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, st())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                lib.ishara_op_dense_bwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, st())
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(name, []).append(e0.elapsed_time(e1) / 10 * 1e3)
+    lib.ishara_debug_force_regstage(1)
+    print(f"bwd M{M} K{K} N{N} (dgrad NT + wgrad TN + reduce + shadows): " + "  ".join(f"{k}={min(v):.0f}us" for k, v in res.items()))
