@@ -869,3 +869,50 @@ int launch_se_bwd(const float* dse, const float* gap, float invT, const float* W
     hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (2 * C + 2 * R) * sizeof(float), s, dse, gap, invT, W1, W2, hid_pre, se, dW1, db1, dW2, db2, dgapT, C, R);
     return LAUNCH_OK();
 }
+
+// =====================================================================================
+// Small streaming passes that materialise an operand transform once so that every GEMM
+// (forward, dgrad and wgrad) runs its fast untransformed path:
+//   MAP_SWISH    y = swish(x)                  (Squeezeformer conv3 input)
+//   MAP_ROWSCALE y = x * rs[row / T]           (drop-path applied to the incoming gradient)
+//   MAP_DROPMASK y = x * mask(row, col)        (inverted dropout applied to the incoming gradient)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void map_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int op, const float* __restrict__ rs,
+                                                       DropSpec drop, int M, int Tn, int C) {
+    const int nch = C >> 3;
+    const int cpr = min(nch, 256), rpb = 256 / cpr;
+    const int cl = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    if (rl >= rpb) return;
+    for (int row = blockIdx.x * rpb + rl; row < M; row += gridDim.x * rpb) {
+        float sc = 1.f;
+        uint32_t rk = 0;
+        if (op == MAP_ROWSCALE) sc = rs[row / Tn];
+        else if (op == MAP_DROPMASK) rk = rng_row_key(drop.key, (uint32_t)row);
+        for (int chunk = cl; chunk < nch; chunk += cpr) {
+            const size_t off = (size_t)row * C + chunk * 8;
+            float v[8];
+            load8(x + off, v);
+            if (op == MAP_SWISH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+            } else if (op == MAP_ROWSCALE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= sc;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = rng_keep(rk, (uint32_t)(chunk * 8 + e), drop.thr) ? v[e] * drop.scale : 0.f;
+            }
+            store8(y + off, v);
+        }
+    }
+}
+
+int launch_map_rows(int dt, int op, const void* x, void* y, const float* rs, DropSpec drop, int M, int T, int C, hipStream_t s) {
+    if (C % 8 != 0) { ishara_set_error("map_rows: C%%8 != 0"); return -1; }
+    const int cpr = min(C / 8, 256), rpb = 256 / cpr;
+    const int grid = max(1, min((M + rpb - 1) / rpb, 4096));
+    if (dt == DT_BF16) hipLaunchKernelGGL(map_rows_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, op, rs, drop, M, T, C);
+    else hipLaunchKernelGGL(map_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, op, rs, drop, M, T, C);
+    return LAUNCH_OK();
+}

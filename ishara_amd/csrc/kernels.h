@@ -87,6 +87,9 @@ int launch_sample_affine(int dt, const void* x, const float* P, const float* Q, 
                          int B, int T, int C, hipStream_t s);
 // y = x*a[c] + b[c]
 int launch_col_affine(int dt, const void* x, const float* a, const float* b, void* y, int M, int C, hipStream_t s);
+enum : int { MAP_SWISH = 0, MAP_ROWSCALE = 1, MAP_DROPMASK = 2 };
+// y = swish(x) | x * rs[row / T] | x * dropmask(row, col)   — one streaming pass over [M, C]
+int launch_map_rows(int dt, int op, const void* x, void* y, const float* rs, DropSpec drop, int M, int T, int C, hipStream_t s);
 // per-sample reductions over t: S1[b,c] = sum_t dy ; S2[b,c] = sum_t dy * other   (other optional,
 // normalised as (other-mean[c])*rstd[c] when mean != nullptr)
 int launch_sample_reduce(int dt, const void* dy, const void* other, const float* mean, const float* rstd,

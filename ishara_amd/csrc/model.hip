@@ -95,11 +95,11 @@ struct MHSA {
 };
 struct SqzConv {
     Norm ln; DenseW Wc1, Wc3; int dw = -1, seW1 = -1, seb1 = -1, seW2 = -1, seb2 = -1; int k = 0, R = 0;
-    Buf xn, mean, rstd, zc, zd, u3, gap, hid, se, out;
+    Buf xn, mean, rstd, zc, zd, hd, u3, gap, hid, se, out;
 };
 struct ConfConv {
     DenseW Wp1, Wp2; int dw = -1, dwb = -1; BNp bn; Norm ln; int k = 0;
-    Buf g, v, ssum, ssq, mean, rstd, a, bsh, r, lnmean, lnrstd, out;
+    Buf g, v, bnv, ssum, ssq, mean, rstd, a, bsh, r, lnmean, lnrstd, out;
 };
 struct Layer {            // one entry of the sequential graph
     enum Kind { CONV, SQZ, CONF } kind;
@@ -340,14 +340,14 @@ static void plan_workspace(ishara_model* m) {
         SqzConv& c = sb.conv;
         const int de = c.Wc1.N;
         c.xn = m->act(d); c.mean = m->f32(Mx); c.rstd = m->f32(Mx);
-        c.zc = m->act(de); c.zd = m->act(de); c.u3 = m->act(d);
+        c.zc = m->act(de); c.zd = m->act(de); c.hd = m->act(de); c.u3 = m->act(d);
         c.gap = m->f32((size_t)B * d); c.hid = m->f32((size_t)B * c.R); c.se = m->f32((size_t)B * d); c.out = m->act(d);
         plan_ffn_act(sb.ffn2);
     }
     for (auto& cb : m->conf) {
         plan_ffn_act(cb.ffn1); plan_mhsa_act(cb.mha);
         ConfConv& c = cb.conv;
-        c.g = m->act(2 * d); c.v = m->act(d);
+        c.g = m->act(2 * d); c.v = m->act(d); c.bnv = m->act(d);
         c.ssum = m->f32((size_t)B * d); c.ssq = m->f32((size_t)B * d);
         c.mean = m->f32(d); c.rstd = m->f32(d); c.a = m->f32(d); c.bsh = m->f32(d);
         c.r = m->act(d); c.lnmean = m->f32(Mx); c.lnrstd = m->f32(Mx); c.out = m->act(d);
@@ -527,7 +527,8 @@ static int sqzconv_fwd(ishara_model* m, SqzConv& c, const Run& r, const void* x)
     CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, x, m->P(c.ln.gamma), m->P(c.ln.beta), 1e-6f, m->W(c.xn), m->Wf(c.mean), m->Wf(c.rstd), r.M, d, m->s));
     CK(gemm_fwd(m, c.Wc1, m->W(c.xn), dt, m->W(c.zc), dt, r.M, OP_NONE, no, e0));
     CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(c.zc), m->P(c.dw), nullptr, m->W(c.zd), nullptr, nullptr, B, T, de, c.k, c.k - 1, m->s));
-    CK(gemm_fwd(m, c.Wc3, m->W(c.zd), dt, m->W(c.u3), dt, r.M, OP_SWISH, no, e0));
+    CKP(m, "map_rows", 2.0 * r.M * de * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_SWISH, m->W(c.zd), m->W(c.hd), nullptr, DropSpec{0, 0, 1.f}, r.M, T, de, m->s));
+    CK(gemm_fwd(m, c.Wc3, m->W(c.hd), dt, m->W(c.u3), dt, r.M, OP_NONE, no, e0));
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(c.u3), nullptr, nullptr, nullptr, m->Wf(c.gap), nullptr, B, T, d, m->s));
     CKP(m, "se_fwd", 0, 0, launch_se_fwd(m->Wf(c.gap), 1.f / T, m->P(c.seW1), m->P(c.seb1), m->P(c.seW2), m->P(c.seb2), m->Wf(c.hid), m->Wf(c.se), B, d, c.R, m->s));
     CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, m->W(c.u3), m->Wf(c.se), nullptr, x, m->W(c.out), B, T, d, m->s));
@@ -543,9 +544,9 @@ static int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* 
     CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), B, T, d, c.k, (c.k - 1) / 2, m->s));
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), 1e-3f, 0.99f,
                           m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s));
-    OpArgs oa; oa.c1 = m->Wf(c.a); oa.c0 = m->Wf(c.bsh);
+    CKP(m, "col_affine", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_col_affine(dt, m->W(c.v), m->Wf(c.a), m->Wf(c.bsh), m->W(c.bnv), r.M, d, m->s));
     EpiArgs e2; e2.resid = x;
-    CK(gemm_fwd(m, c.Wp2, m->W(c.v), dt, m->W(c.r), dt, r.M, OP_COLAFFINE, oa, e2));
+    CK(gemm_fwd(m, c.Wp2, m->W(c.bnv), dt, m->W(c.r), dt, r.M, OP_NONE, no, e2));
     CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, m->W(c.r), m->P(c.ln.gamma), m->P(c.ln.beta), 1e-3f, m->W(c.out), m->Wf(c.lnmean), m->Wf(c.lnrstd), r.M, d, m->s));
     return 0;
 }
@@ -596,10 +597,14 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
     const int d = m->d, c = 2 * d, B = r.B, T = m->T, dt = m->dt;
     OpArgs no;
     const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
-    EpiArgs e1; if (ds.thr) { e1.rowscale = m->Wf(cb.rs); e1.T = T; }
-    CK(gemm_dgrad(m, cb.W2, g, dt, m->W(m->t1), r.M, OP_NONE, no, e1));                        // dh4
-    OpArgs ob; int bop = OP_NONE; if (ds.thr) { ob.rs = m->Wf(cb.rs); ob.T = T; bop = OP_ROWSCALE; }
-    CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, g, dt, bop, ob, r.M));
+    const void* gs = g;                                  // gradient through the drop-path: dY * rs[b]
+    if (ds.thr) {
+        CKP(m, "map_rows", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_ROWSCALE, g, m->W(m->t3), m->Wf(cb.rs), ds, r.M, T, d, m->s));
+        gs = m->W(m->t3);
+    }
+    EpiArgs e1;
+    CK(gemm_dgrad(m, cb.W2, gs, dt, m->W(m->t1), r.M, OP_NONE, no, e1));                       // dh4
+    CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
     CKP(m, "eca_bn_bwd_finalize", 0, 0, launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
                                   m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), B, T, c, m->s));
@@ -614,11 +619,17 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
 static int ffn_bwd(ishara_model* m, FFN& f, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt;
     OpArgs no;
-    OpArgs oo; int oop = OP_NONE;
-    if (f.has_out_drop) { oo.drop = dspec(r, f.site_out, m->cfg.dropout_rate); if (oo.drop.thr) oop = OP_DROPMASK; }
+    const void* gs = g;                                  // gradient through the outer dropout
+    if (f.has_out_drop) {
+        const DropSpec od = dspec(r, f.site_out, m->cfg.dropout_rate);
+        if (od.thr) {
+            CKP(m, "map_rows", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_DROPMASK, g, m->W(m->t3), nullptr, od, r.M, m->T, m->d, m->s));
+            gs = m->W(m->t3);
+        }
+    }
     EpiArgs e1; e1.drop = dspec(r, f.site_in, m->cfg.dropout_rate); e1.dact = DACT_SWISH; e1.aux = m->W(f.za);
-    CK(gemm_dgrad(m, f.Wb, g, dt, m->W(m->t1), r.M, oop, oo, e1));                              // dza
-    CK(gemm_wgrad(m, f.Wb, m->W(f.u), dt, OP_NONE, no, g, dt, oop, oo, r.M));
+    CK(gemm_dgrad(m, f.Wb, gs, dt, m->W(m->t1), r.M, OP_NONE, no, e1));                         // dza
+    CK(gemm_wgrad(m, f.Wb, m->W(f.u), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
     EpiArgs e0;
     CK(gemm_dgrad(m, f.Wa, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));              // dxn
     CK(gemm_wgrad(m, f.Wa, m->W(f.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
@@ -629,10 +640,16 @@ static int ffn_bwd(ishara_model* m, FFN& f, const Run& r, const void* x, const v
 static int mhsa_bwd(ishara_model* m, MHSA& a, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt;
     OpArgs no; EpiArgs e0;
-    OpArgs oo; int oop = OP_NONE;
-    if (a.has_out_drop) { oo.drop = dspec(r, a.site_out, m->cfg.dropout_rate); if (oo.drop.thr) oop = OP_DROPMASK; }
-    CK(gemm_dgrad(m, a.Wp, g, dt, m->W(m->t1), r.M, oop, oo, e0));                              // do
-    CK(gemm_wgrad(m, a.Wp, m->W(a.o), dt, OP_NONE, no, g, dt, oop, oo, r.M));
+    const void* gs = g;
+    if (a.has_out_drop) {
+        const DropSpec od = dspec(r, a.site_out, m->cfg.dropout_rate);
+        if (od.thr) {
+            CKP(m, "map_rows", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_DROPMASK, g, m->W(m->t3), nullptr, od, r.M, m->T, m->d, m->s));
+            gs = m->W(m->t3);
+        }
+    }
+    CK(gemm_dgrad(m, a.Wp, gs, dt, m->W(m->t1), r.M, OP_NONE, no, e0));                         // do
+    CK(gemm_wgrad(m, a.Wp, m->W(a.o), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
     const float scale = 1.0f / sqrtf((float)m->d);
     CKP(m, "attn_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 10.0 * r.B * m->H * (double)m->T * m->T * m->dh, launch_attn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta), m->W(m->t2),
                        r.B, m->H, m->T, m->dh, scale, dspec(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, m->s));
@@ -651,7 +668,7 @@ static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x,
     CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, g, m->Wf(c.se), m->Wf(m->dgapT), nullptr, m->W(m->t1), B, T, d, m->s));           // du3
     EpiArgs e1; e1.dact = DACT_SWISH; e1.aux = m->W(c.zd);
     CK(gemm_dgrad(m, c.Wc3, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e1));                                // dzd
-    CK(gemm_wgrad(m, c.Wc3, m->W(c.zd), dt, OP_SWISH, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    CK(gemm_wgrad(m, c.Wc3, m->W(c.hd), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
     CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, B, T, de, c.k, c.k - 1, m->s));   // dzc
     CK(gemm_dgrad(m, c.Wc1, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // dxn
     CK(gemm_wgrad(m, c.Wc1, m->W(c.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
@@ -664,8 +681,7 @@ static int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* 
     OpArgs no; EpiArgs e0;
     CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), m->Wf(m->slab), r.M, d, m->s));   // dr
     CK(gemm_dgrad(m, c.Wp2, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // d bn(v)
-    OpArgs oa; oa.c1 = m->Wf(c.a); oa.c0 = m->Wf(c.bsh);
-    CK(gemm_wgrad(m, c.Wp2, m->W(c.v), dt, OP_COLAFFINE, oa, m->W(m->t1), dt, OP_NONE, no, r.M));
+    CK(gemm_wgrad(m, c.Wp2, m->W(c.bnv), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
     CKP(m, "bn_bwd_finalize", 0, 0, launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(c.bn.gamma), m->G(c.bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
     CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv

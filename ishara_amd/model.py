@@ -380,7 +380,7 @@ def make_config(dim=256, num_conv_squeeze_blocks=2, num_conv_conform_blocks=2, k
                 num_conv_per_block=3, dropout_rate=0.2, num_heads=8, expansion_factor=2, transformer_kernel_size=15,
                 input_shape=(176, 276), num_classes=60, top_dim=0, squeeze_expansion=0, conformer_expansion=0,
                 head_dropout=0.4, conformer_attn_dropout=0.1, dtype="bf16", max_batch=64, max_label_len=64,
-                attn_impl=0) -> _lib.Config:
+                attn_impl=1) -> _lib.Config:
     c = _lib.Config()
     c.dim, c.num_conv_squeeze_blocks, c.num_conv_conform_blocks = dim, num_conv_squeeze_blocks, num_conv_conform_blocks
     ks = list(kernel_sizes)

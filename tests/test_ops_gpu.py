@@ -158,9 +158,13 @@ def _attn_ref(qkv, B, H, T, dh, scale, mask):
     return (a @ v).permute(0, 2, 1, 3).reshape(B * T, d)
 
 
+@pytest.mark.parametrize("impl", [0, 1])   # 0 lane-split VALU kernels, 1 MFMA flash kernels (bf16, dh 32/64)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("B,H,T,dh,rate", [(2, 8, 176, 8, 0.0), (2, 4, 64, 32, 0.2), (1, 2, 384, 64, 0.1), (3, 8, 16, 16, 0.0)])
-def test_attention(lib, dt, B, H, T, dh, rate):
+@pytest.mark.parametrize("B,H,T,dh,rate", [(2, 8, 176, 8, 0.0), (2, 4, 64, 32, 0.2), (1, 2, 384, 64, 0.1), (3, 8, 16, 16, 0.0),
+                                           (2, 3, 176, 32, 0.2), (1, 2, 512, 64, 0.0), (2, 2, 384, 32, 0.0)])
+def test_attention(lib, dt, B, H, T, dh, rate, impl):
+    if impl == 1 and (dt != "bf16" or dh not in (32, 64)):
+        pytest.skip("MFMA attention: bf16, head dim 32/64")
     from oracle import rng
     code, tdt = DT[dt]
     d = H * dh
@@ -173,7 +177,7 @@ def test_attention(lib, dt, B, H, T, dh, rate):
     o = torch.empty(B * T, d, dtype=tdt, device="cuda")
     sc = torch.empty(int(lib.ishara_op_attn_scratch_bytes(B, H, T, dh)) + 256, dtype=torch.uint8, device="cuda")
     scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
-    _lib.check(lib.ishara_op_attn_fwd(code, _lib.ptr(qd), _lib.ptr(o), B, H, T, dh, C.c_float(scale), seed, site, C.c_float(rate), 0, scp, stream()))
+    _lib.check(lib.ishara_op_attn_fwd(code, _lib.ptr(qd), _lib.ptr(o), B, H, T, dh, C.c_float(scale), seed, site, C.c_float(rate), impl, scp, stream()))
     mask = None
     if rate > 0:
         mask = torch.from_numpy(rng.scaled_mask(seed, site, B * H * T, T, rate, dtype=np.float64)).view(B, H, T, T)
@@ -182,8 +186,9 @@ def test_attention(lib, dt, B, H, T, dh, rate):
     close(o, ref, "attn_fwd", **TOL[dt])
     ref.backward(dout.double())
     dqkv = torch.empty(B * T, 3 * d, dtype=tdt, device="cuda")
-    _lib.check(lib.ishara_op_attn_bwd(code, _lib.ptr(o), _lib.ptr(dd), _lib.ptr(dqkv), B, H, T, dh, C.c_float(scale), seed, site, C.c_float(rate), 0, scp, stream()))
-    close(dqkv, qr.grad, "attn_dqkv", **TOL[dt])
+    _lib.check(lib.ishara_op_attn_bwd(code, _lib.ptr(o), _lib.ptr(dd), _lib.ptr(dqkv), B, H, T, dh, C.c_float(scale), seed, site, C.c_float(rate), impl, scp, stream()))
+    btol = TOL[dt] if dt == "f32" else dict(rtol=3e-2, atol=6e-2)     # bf16: o, dout and P are rounded before the 5 backward products
+    close(dqkv, qr.grad, "attn_dqkv", **btol)
 
 
 @pytest.mark.parametrize("B,T,L", [(4, 176, 64), (3, 384, 64), (2, 16, 8)])
