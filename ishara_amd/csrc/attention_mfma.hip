@@ -184,6 +184,350 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
     }
 }
 
+// =====================================================================================
+// Backward: two MFMA kernels, both recomputing P from Q, K and the forward's LSE.
+//   dq kernel  (query-stationary, same sweep as the forward): S^T = K.Q^T, dP^T = V.dO^T,
+//              dS^T = P^T o (dP^T o D - delta) * scale, dQ^T += K^T.dS^T          (+ writes delta)
+//   dkv kernel (key-stationary, sweeps query chunks): S = Q.K^T, dP = dO.V^T,
+//              dV^T += dO^T.(P o D), dK^T += Q^T.dS
+// Operands that are needed transposed (V rows / K^T in the first, dO^T / Q^T in the second) are
+// fetched from the row-major LDS chunk with ds_read_b64_tr_b16; score-shaped accumulators feed
+// the next product as its B operand in registers (same k-slot permutation as the forward).
+// No atomics: dq is complete in the first kernel, dk/dv in the second.
+// =====================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4_;
+typedef __attribute__((ext_vector_type(8))) short s16x8_;
+
+// transposed fragment: 16 columns starting at col0 of rows {r0 + q', r1 + q'} (q' = 0..3) of a row-major bf16 tile
+DEVI bf16x8 trfrag(const bf16* tile, int ld, int r0, int r1, int col0, int lane) {
+    const int qq = (lane >> 2) & 3, pp = lane & 3;
+    const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(tile + (r0 + qq) * ld + col0 + 4 * pp));
+    const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(tile + (r1 + qq) * ld + col0 + 4 * pp));
+    return __builtin_bit_cast(bf16x8, (s16x8_)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+DEVI bf16x8 pack8(const float (&a)[4], const float (&b)[4]) {
+    u32x4 w;
+    w.x = pk2(a[0], a[1]); w.y = pk2(a[2], a[3]); w.z = pk2(b[0], b[1]); w.w = pk2(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
+                                                               const bf16* __restrict__ o, const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                               float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                               int H, int Tn, float scale, DropSpec drop) {
+    constexpr int KS = DH / 32, DT = DH / 16, NP = DH / 32;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[2][AF_KC * DH];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[2][DH * AF_KC];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int qbase = blockIdx.x * AF_QB + wid * 32;
+    const int dmodel = H * DH;
+    const bf16* qb = q + (size_t)bh * Tn * DH;
+    const bf16* kb = k + (size_t)bh * Tn * DH;
+    const bf16* vb = vt + (size_t)bh * DH * Tn;
+
+    bf16x8 qf[2][KS], dof[2][KS];
+    float dlt[2], lsl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qrow = min(qbase + 16 * t + c, Tn - 1);
+        const size_t orow = ((size_t)b * Tn + qrow) * dmodel + h * DH;
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[t][s] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * DH + 32 * s + 8 * g);
+            dof[t][s] = *reinterpret_cast<const bf16x8*>(dout + orow + 32 * s + 8 * g);
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + orow + 32 * s + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)dof[t][s][e] * (float)of[e];
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        dlt[t] = part;
+        lsl[t] = lse[(size_t)bh * Tn + qrow] * 1.4426950408889634f;
+        if (g == 0 && qbase + 16 * t + c < Tn) delta[(size_t)bh * Tn + qrow] = part;
+    }
+    f32x4 acc[DT][2];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[d][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float cs = scale * 1.4426950408889634f;
+    const int nch = (Tn + AF_KC - 1) / AF_KC;
+
+    u32x4 rk[NP], rv[NP];
+#define DQ_GLOAD(ch)                                                                                              \
+    {                                                                                                             \
+        const int key0_ = (ch) * AF_KC;                                                                           \
+        _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                          \
+            const int pi = tid + 256 * u;                                                                         \
+            const int key = pi / (DH / 8), part = pi % (DH / 8);                                                  \
+            rk[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)min(key0_ + key, Tn - 1) * DH + part * 8);       \
+            const int dv = pi >> 3, kk = key0_ + (pi & 7) * 8;                                                    \
+            rv[u] = kk < Tn ? *reinterpret_cast<const u32x4*>(vb + (size_t)dv * Tn + kk) : u32x4{0u, 0u, 0u, 0u}; \
+        }                                                                                                         \
+    }
+#define DQ_LSTORE(buf)                                                                                            \
+    {                                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                          \
+            const int pi = tid + 256 * u;                                                                         \
+            *reinterpret_cast<u32x4*>(&Ks[buf][pi * 8]) = rk[u];                                                  \
+            *reinterpret_cast<u32x4*>(&Vs[buf][pi * 8]) = rv[u];                                                  \
+        }                                                                                                         \
+    }
+    DQ_GLOAD(0);
+    DQ_LSTORE(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool more = ch + 1 < nch;
+        if (more) DQ_GLOAD(ch + 1);
+        const bf16* Kc = Ks[ch & 1];
+        const bf16* Vc = Vs[ch & 1];
+        const int key0 = ch * AF_KC;
+        bf16x8 dsb[2][2];
+        {
+            f32x4 sacc[4][2], dpa[4][2];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                bf16x8 kf[KS], vf[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    kf[s] = *reinterpret_cast<const bf16x8*>(Kc + (16 * kt + c) * DH + 32 * s + 8 * g);
+                    vf[s] = trfrag(Vc, AF_KC, 32 * s + 8 * g, 32 * s + 8 * g + 4, 16 * kt, lane);    // V[key c][dv 32s+8g..+7]
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    sacc[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dpa[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        sacc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[t][s], sacc[kt][t], 0, 0, 0);
+                        dpa[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s], dof[t][s], dpa[kt][t], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t rkey = rng_row_key(drop.key, (uint32_t)(bh * Tn + qbase + 16 * t + c));
+                float ds[4][4];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + 16 * kt + 4 * g + r;
+                        const float pv = key < Tn ? exp2f(sacc[kt][t][r] * cs - lsl[t]) : 0.f;
+                        float dp = dpa[kt][t][r];
+                        if (drop.thr) dp = rng_keep(rkey, (uint32_t)key, drop.thr) ? dp * drop.scale : 0.f;
+                        ds[kt][r] = pv * (dp - dlt[t]) * scale;
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) dsb[t][ks] = pack8(ds[2 * ks], ds[2 * ks + 1]);
+            }
+        }
+        // dQ^T[dh][q] += K^T[dh][key] . dS^T[key][q]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const bf16x8 ktf = trfrag(Kc, DH, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsb[t][ks], acc[d][t], 0, 0, 0);
+            }
+        if (more) DQ_LSTORE((ch + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qrow = qbase + 16 * t + c;
+        if (qrow < Tn) {
+            bf16* drow = dqkv + ((size_t)b * Tn + qrow) * (3 * dmodel) + h * 3 * DH;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                bf16x4 w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (bf16)acc[d][t][r];
+                *reinterpret_cast<bf16x4*>(drow + 16 * d + 4 * g) = w;
+            }
+        }
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
+                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                const float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                                int H, int Tn, float scale, DropSpec drop) {
+    constexpr int KS = DH / 32, DT = DH / 16, NP = DH / 32;
+    __shared__ __attribute__((aligned(16))) bf16 Qs[2][AF_KC * DH];
+    __shared__ __attribute__((aligned(16))) bf16 Ds[2][AF_KC * DH];
+    __shared__ float Ls[2][AF_KC], Dl[2][AF_KC];
+    __shared__ uint32_t Rk[2][AF_KC];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int kbase = blockIdx.x * AF_QB + wid * 32;
+    const int dmodel = H * DH;
+    const bf16* qb = q + (size_t)bh * Tn * DH;
+    const bf16* kb = k + (size_t)bh * Tn * DH;
+    const bf16* vb = vt + (size_t)bh * DH * Tn;
+    const bf16* dob = dout + (size_t)b * Tn * dmodel + h * DH;
+
+    bf16x8 kf[2][KS], vf[2][KS];          // B operands: K[key c][dh 32s+8g..], V[key c][dv 32s+8g..]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int key = min(kbase + 16 * t + c, Tn - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kf[t][s] = *reinterpret_cast<const bf16x8*>(kb + (size_t)key * DH + 32 * s + 8 * g);
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = vb[(size_t)(32 * s + 8 * g + e) * Tn + key];
+            vf[t][s] = v;
+        }
+    }
+    f32x4 adv[DT][2], adk[DT][2];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { adv[d][t] = f32x4{0.f, 0.f, 0.f, 0.f}; adk[d][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float cs = scale * 1.4426950408889634f;
+    const int nch = (Tn + AF_KC - 1) / AF_KC;
+
+    u32x4 rq[NP], rd[NP];
+    float rl = 0.f;
+    uint32_t rr = 0;
+#define DKV_GLOAD(ch)                                                                                             \
+    {                                                                                                             \
+        const int q0_ = (ch) * AF_KC;                                                                             \
+        _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                          \
+            const int pi = tid + 256 * u;                                                                         \
+            const int row = min(q0_ + pi / (DH / 8), Tn - 1), part = pi % (DH / 8);                               \
+            rq[u] = *reinterpret_cast<const u32x4*>(qb + (size_t)row * DH + part * 8);                            \
+            rd[u] = *reinterpret_cast<const u32x4*>(dob + (size_t)row * dmodel + part * 8);                       \
+        }                                                                                                         \
+        const int qr_ = min(q0_ + (tid & 63), Tn - 1);                                                            \
+        if (tid < 64) rl = lse[(size_t)bh * Tn + qr_] * 1.4426950408889634f;                                      \
+        else if (tid < 128) rl = delta[(size_t)bh * Tn + qr_];                                                    \
+        else if (tid < 192) rr = rng_row_key(drop.key, (uint32_t)(bh * Tn + q0_ + (tid & 63)));                  \
+    }
+#define DKV_LSTORE(buf)                                                                                           \
+    {                                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                          \
+            const int pi = tid + 256 * u;                                                                         \
+            *reinterpret_cast<u32x4*>(&Qs[buf][pi * 8]) = rq[u];                                                  \
+            *reinterpret_cast<u32x4*>(&Ds[buf][pi * 8]) = rd[u];                                                  \
+        }                                                                                                         \
+        if (tid < 64) Ls[buf][tid] = rl;                                                                          \
+        else if (tid < 128) Dl[buf][tid - 64] = rl;                                                               \
+        else if (tid < 192) Rk[buf][tid - 128] = rr;                                                              \
+    }
+    DKV_GLOAD(0);
+    DKV_LSTORE(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool more = ch + 1 < nch;
+        if (more) DKV_GLOAD(ch + 1);
+        const bf16* Qc = Qs[ch & 1];
+        const bf16* Dc = Ds[ch & 1];
+        const float* Lc = Ls[ch & 1];
+        const float* Dlc = Dl[ch & 1];
+        const uint32_t* Rc = Rk[ch & 1];
+        const int q0 = ch * AF_KC;
+        bf16x8 pdb[2][2], dsb[2][2];
+        {
+            f32x4 sacc[4][2], dpa[4][2];
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                bf16x8 qfr[KS], dfr[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    qfr[s] = *reinterpret_cast<const bf16x8*>(Qc + (16 * qt + c) * DH + 32 * s + 8 * g);
+                    dfr[s] = *reinterpret_cast<const bf16x8*>(Dc + (16 * qt + c) * DH + 32 * s + 8 * g);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    sacc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dpa[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        sacc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[s], kf[t][s], sacc[qt][t], 0, 0, 0);
+                        dpa[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[s], vf[t][s], dpa[qt][t], 0, 0, 0);
+                    }
+                }
+            }
+            // element (qt, t, r): query q0 + 16qt + 4g + r, key kbase + 16t + c
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t key = (uint32_t)(kbase + 16 * t + c);
+                float pd[4][4], ds[4][4];
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ql = 16 * qt + 4 * g + r;
+                        const float pv = (q0 + ql < Tn) ? exp2f(sacc[qt][t][r] * cs - Lc[ql]) : 0.f;
+                        float dp = dpa[qt][t][r], pdv = pv;
+                        if (drop.thr) {
+                            const bool keep = rng_keep(Rc[ql], key, drop.thr);
+                            dp = keep ? dp * drop.scale : 0.f;
+                            pdv = keep ? pv * drop.scale : 0.f;
+                        }
+                        pd[qt][r] = pdv;
+                        ds[qt][r] = pv * (dp - Dlc[ql]) * scale;
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) { pdb[t][ks] = pack8(pd[2 * ks], pd[2 * ks + 1]); dsb[t][ks] = pack8(ds[2 * ks], ds[2 * ks + 1]); }
+            }
+        }
+        // dV^T[dv][key] += dO^T[dv][q].(P o D)[q][key] ; dK^T[dh][key] += Q^T[dh][q].dS[q][key]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const bf16x8 dtf = trfrag(Dc, DH, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
+                const bf16x8 qtf = trfrag(Qc, DH, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    adv[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtf, pdb[t][ks], adv[d][t], 0, 0, 0);
+                    adk[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsb[t][ks], adk[d][t], 0, 0, 0);
+                }
+            }
+        if (more) DKV_LSTORE((ch + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int key = kbase + 16 * t + c;
+        if (key < Tn) {
+            bf16* drow = dqkv + ((size_t)b * Tn + key) * (3 * dmodel) + h * 3 * DH;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                bf16x4 wk, wv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { wk[r] = (bf16)adk[d][t][r]; wv[r] = (bf16)adv[d][t][r]; }
+                *reinterpret_cast<bf16x4*>(drow + DH + 16 * d + 4 * g) = wk;
+                *reinterpret_cast<bf16x4*>(drow + 2 * DH + 16 * d + 4 * g) = wv;
+            }
+        }
+    }
+}
+
+int launch_attn_bwd_mfma(const void* q, const void* k, const void* vt, const void* o, const void* dout, const float* lse,
+                         float* delta, void* dqkv, int B, int H, int T, int dh, float scale, DropSpec drop, hipStream_t s) {
+    if (T % 8 != 0) { ishara_set_error("attn_bwd_mfma: T %% 8 != 0"); return -1; }
+    dim3 grid((T + AF_QB - 1) / AF_QB, B * H);
+    if (dh == 32) {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<32>, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)o, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, T, scale, drop);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<32>, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)dout, lse, (const float*)delta, (bf16*)dqkv, H, T, scale, drop);
+    } else if (dh == 64) {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<64>, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)o, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, T, scale, drop);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<64>, grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)dout, lse, (const float*)delta, (bf16*)dqkv, H, T, scale, drop);
+    } else { ishara_set_error("attn_bwd_mfma: head dim %d unsupported (32, 64)", dh); return -1; }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_attn_fwd_mfma(const void* q, const void* k, const void* vt, void* o, float* lse,
                          int B, int H, int T, int dh, float scale, DropSpec drop, hipStream_t s) {
     if (T % 8 != 0) { ishara_set_error("attn_fwd_mfma: T %% 8 != 0"); return -1; }
