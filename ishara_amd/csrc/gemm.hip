@@ -445,27 +445,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const TA* __restrict__ A, 
 // drains its accumulators through a private fp32 LDS stage (no block barrier) into the fused
 // epilogue with 16-byte coalesced stores.
 // ---------------------------------------------------------------------------------
-#define GL_STAGE 24576          // A 64 rows x 128 B + B 128 rows x 128 B
-#define GL_NSTAGE 3
+#define GL_STAGE 12288          // A 64 rows x 64 B + B 128 rows x 64 B   (K tile = 32 bf16 / 16 f32)
+#define GL_NSTAGE 4
+DEVI int gl_f(int row) { return ((row >> 3) & 1) << 1; }      // conflict-free slot swizzle for 64-byte rows (brute-forced)
 
 template <typename TM>
 DEVI void glds_issue(const TM* __restrict__ A, const TM* __restrict__ Bt, int M, int K, int ldb, int m0, int n0, int kt,
                      char* stage, int wid, int lane) {
-    constexpr int EPC = MmaCfg<TM>::EPC, BK = MmaCfg<TM>::BK;
-    const int r = lane >> 3, sp = lane & 7;
-    const int kcol = kt * BK + ((sp ^ r) * EPC);          // logical 16-byte slot that lands in physical slot sp of row r
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {                          // A: 8 pieces of 8 rows; wave takes pieces wid, wid+4
-        const int j = wid + 4 * u;
-        const int row = min(m0 + 8 * j + r, M - 1);
+    constexpr int EPC = MmaCfg<TM>::EPC, BKH = MmaCfg<TM>::BK / 2;
+    const int r = lane >> 2, sp = lane & 3;                 // 16 rows x 4 slots per 1 KB piece
+    const int kcol = kt * BKH + ((sp ^ gl_f(r)) * EPC);     // logical slot that lands in physical slot sp of row r
+    {                                                       // A: 4 pieces of 16 rows, one per wave
+        const int row = min(m0 + 16 * wid + r, M - 1);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)row * K + kcol),
-                                         (__attribute__((address_space(3))) void*)(stage + j * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(stage + wid * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                          // B: 16 pieces; wave takes wid, wid+4, wid+8, wid+12
+    for (int u = 0; u < 2; ++u) {                           // B: 8 pieces, two per wave
         const int j = wid + 4 * u;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bt + (size_t)(n0 + 8 * j + r) * ldb + kcol),
-                                         (__attribute__((address_space(3))) void*)(stage + 8192 + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bt + (size_t)(n0 + 16 * j + r) * ldb + kcol),
+                                         (__attribute__((address_space(3))) void*)(stage + 4096 + j * 1024), 16, 0, 0);
     }
 }
 
@@ -473,38 +472,35 @@ template <typename TM>
 DEVI void mma_tile_2x4(const char* ldsA, const char* ldsB, int wr, int wc, int lane, f32x4 (&acc)[2][4]) {
     const int r = lane & 15, g = lane >> 4;
     if constexpr (is_bf16_t<TM>::value) {
+        bf16x8 a[2], b[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 a[2], b[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wr * 32 + 16 * i + r;
-                a[i] = *reinterpret_cast<const bf16x8*>(ldsA + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wc * 64 + 16 * j + r;
-                b[j] = *reinterpret_cast<const bf16x8*>(ldsB + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            const int row = wr * 32 + 16 * i + r;
+            a[i] = *reinterpret_cast<const bf16x8*>(ldsA + row * 64 + ((g ^ gl_f(row)) << 4));
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wc * 64 + 16 * j + r;
+            b[j] = *reinterpret_cast<const bf16x8*>(ldsB + row * 64 + ((g ^ gl_f(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < 4; ++s) {
             float a[2], b[4];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wr * 32 + 16 * i + r;
-                a[i] = *reinterpret_cast<const float*>(ldsA + row * 128 + ((s ^ (row & 7)) << 4) + g * 4);
+                a[i] = *reinterpret_cast<const float*>(ldsA + row * 64 + ((s ^ gl_f(row)) << 4) + g * 4);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = wc * 64 + 16 * j + r;
-                b[j] = *reinterpret_cast<const float*>(ldsB + row * 128 + ((s ^ (row & 7)) << 4) + g * 4);
+                b[j] = *reinterpret_cast<const float*>(ldsB + row * 64 + ((s ^ gl_f(row)) << 4) + g * 4);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -516,10 +512,10 @@ DEVI void mma_tile_2x4(const char* ldsA, const char* ldsB, int wr, int wc, int l
 }
 
 template <typename TM, typename TC>
-__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const TM* __restrict__ A, const TM* __restrict__ Bt, TC* __restrict__ C,
+__global__ __launch_bounds__(256, 3) void gemm_nt_glds_kernel(const TM* __restrict__ A, const TM* __restrict__ Bt, TC* __restrict__ C,
                                                            int M, int N, int K, int ldb, EpiArgs ea) {
     __shared__ __attribute__((aligned(16))) char smem[GL_NSTAGE * GL_STAGE];
-    constexpr int BK = MmaCfg<TM>::BK;
+    constexpr int BK = MmaCfg<TM>::BK / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
@@ -540,24 +536,30 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const TM* __restrict_
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool ld_on = !(ea.dbg & 4), mma_on = !(ea.dbg & 2);
-    if (ld_on) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, 0, smem, wid, lane);
-    if (nk > 1 && ld_on) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, 1, smem + GL_STAGE, wid, lane);
+    // epilogue operands (bias, residual, act' input, drop-path scale) are requested first: their latency hides under the K loop
+    const int mw = m0 + wr * 32, nw = n0 + wc * 64;
+    EpiRows<TC, 4> er;       // thread -> columns (lane&7)*8.., rows (lane>>3) + 8q
+    er.prefetch(mw + (lane >> 3), 8, nw + (lane & 7) * 8, M, N, ea);
+#pragma unroll
+    for (int st = 0; st < GL_NSTAGE - 1; ++st)
+        if (st < nk && ld_on) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, st, smem + st * GL_STAGE, wid, lane);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // this wave's pieces of tile kt have landed
+        // 3 DMA per wave per K tile; up to two later tiles stay in flight across the barrier
+        const int ahead = min(nk - 1 - kt, GL_NSTAGE - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                          // ... and everyone else's; tile kt-1 fully consumed
-        if (kt + 2 < nk && ld_on) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, kt + 2, smem + ((kt + 2) % GL_NSTAGE) * GL_STAGE, wid, lane);
+        __builtin_amdgcn_s_barrier();                      // tile kt landed for every wave; tile kt-1 fully consumed
+        if (kt + GL_NSTAGE - 1 < nk && ld_on)
+            glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, kt + GL_NSTAGE - 1, smem + ((kt + GL_NSTAGE - 1) % GL_NSTAGE) * GL_STAGE, wid, lane);
         const char* st = smem + (kt % GL_NSTAGE) * GL_STAGE;
-        if (mma_on) mma_tile_2x4<TM>(st, st + 8192, wr, wc, lane, acc);
+        if (mma_on) mma_tile_2x4<TM>(st, st + 4096, wr, wc, lane, acc);
     }
     __syncthreads();     // ring is free: reuse it as four wave-private fp32 stages
     if (ea.dbg & 1) { if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][3][2]); return; }
 
     constexpr int SLD = 68;
     float* stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
-    const int mw = m0 + wr * 32, nw = n0 + wc * 64;
-    EpiRows<TC, 4> er;       // thread -> columns (lane&7)*8.., rows (lane>>3) + 8q
-    er.prefetch(mw + (lane >> 3), 8, nw + (lane & 7) * 8, M, N, ea);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -619,7 +621,7 @@ static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int 
     }
 }
 
-int g_force_regstage = 1;   // 1: register-staged 128x128 kernel (default, faster at K<=768); 0: LDS-DMA 64x128 kernel
+int g_force_regstage = 0;   // 0: LDS-DMA 64x128 kernel whenever eligible (default); 1: always the register-staged 128x128 kernel
 int g_dbg_tn = 0;           // ablation bits for the TN kernel: 1 skip MFMA, 2 skip LDS stores, 4 skip global loads
 
 int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
@@ -631,8 +633,8 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
     if (ea.mode == EPI_QKV && (ea.T % 8 != 0 || N % 8 != 0 || ea.dh % 8 != 0)) {
         ishara_set_error("gemm_nt: QKV split needs T, dh multiples of 8 (T=%d dh=%d)", ea.T, ea.dh); return -1;
     }
-    const int bk = dtM == DT_BF16 ? 64 : 32;
-    if (op == OP_NONE && dtA == dtM && K % bk == 0 && ((uintptr_t)A) % 16 == 0 && !g_force_regstage) {
+    const int bk = dtM == DT_BF16 ? 32 : 16;     // K tile of the LDS-DMA kernel
+    if (op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0 && !g_force_regstage) {
         if (dtM == DT_F32 && dtC == DT_F32) return run_nt_glds<float, float>(A, Bt, C, M, N, K, ldb, ea, s);
         if (dtM == DT_BF16 && dtC == DT_BF16) return run_nt_glds<bf16, bf16>(A, Bt, C, M, N, K, ldb, ea, s);
         if (dtM == DT_BF16 && dtC == DT_F32) return run_nt_glds<bf16, float>(A, Bt, C, M, N, K, ldb, ea, s);

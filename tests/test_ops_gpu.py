@@ -42,7 +42,7 @@ def test_dense_fwd_bwd(lib, dt, M, K, N, act, regstage):
     try:
         _dense_fwd_bwd(lib, dt, M, K, N, act)
     finally:
-        lib.ishara_debug_force_regstage(1)
+        lib.ishara_debug_force_regstage(0)
 
 
 def _dense_fwd_bwd(lib, dt, M, K, N, act):

@@ -32,7 +32,7 @@ for (M, K, N) in shapes:
                 lib.ishara_op_dense_fwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(y), M, K, N, 0, scp, st())
             e1.record(); torch.cuda.synchronize()
             res.setdefault(name, []).append(e0.elapsed_time(e1) / 10 * 1e3)
-    lib.ishara_debug_force_regstage(1)
+    lib.ishara_debug_force_regstage(0)
     gb = (M * K * 2 + M * N * 2) / 1e9
     print(f"M{M} K{K} N{N}: " + "  ".join(f"{k}={min(v):.0f}us" for k, v in res.items()) + f"   [{gb / (min(res['glds']) * 1e-6) / 1e3:.2f} TB/s, includes shadow build+memset]")
 
@@ -47,7 +47,7 @@ for (M, K, N) in [(98304, 256, 512), (98304, 512, 256)]:
     scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
     res = {}
     for rnd in range(3):
-        for name, flag in {"full": 1, "tn-nomma": 1 | (1 << 8), "tn-nolds": 1 | (2 << 8), "tn-noload": 1 | (4 << 8), "tn-nothing": 1 | (7 << 8)}.items():
+        for name, flag in {"full": 0, "tn-regstage": 2}.items():
             lib.ishara_debug_force_regstage(flag)
             for _ in range(2):
                 lib.ishara_op_dense_bwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, st())
@@ -57,5 +57,5 @@ for (M, K, N) in [(98304, 256, 512), (98304, 512, 256)]:
                 lib.ishara_op_dense_bwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, st())
             e1.record(); torch.cuda.synchronize()
             res.setdefault(name, []).append(e0.elapsed_time(e1) / 10 * 1e3)
-    lib.ishara_debug_force_regstage(1)
+    lib.ishara_debug_force_regstage(0)
     print(f"bwd M{M} K{K} N{N} (dgrad NT + wgrad TN + reduce + shadows): " + "  ".join(f"{k}={min(v):.0f}us" for k, v in res.items()))
