@@ -130,6 +130,14 @@ def main():
         ach = by / (avg_ms * 1e-3) / 1e9
         roof = dict(bound="hbm", kernel=fam, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
     roof.update(launches_per_step=rec["launches"], avg_launch_ms=avg_ms, algorithmic_bytes_per_launch=by, flops_per_launch=fl)
+    # HBM traffic of that kernel per launch: from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
+    # command (tools/traffic.py applies the gfx950 corrections); PMC counters cannot be read live from inside the process.
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["kernels"].get(fam)
+        if tr and args.batch == 256 and args.dtype == "bf16":
+            roof["traffic"] = tr["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "metric": "landmark-frames/sec training (B=256,T=384,d=256)", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,

@@ -18,6 +18,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 #define AF_KC 64     // keys per LDS chunk
 #define AF_QB 128    // queries per workgroup
+#define AF_VLD 72    // V^T tile row stride (64 keys + 8 pad): 144-B rows make the 8-byte fragment reads conflict-free
+#define AF_PAD 8     // row-major [64][DH] tiles get DH+8 columns (80-B / 144-B rows): conflict-free 16-byte fragment reads
 
 DEVI uint32_t pk2(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -31,8 +33,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
     constexpr int KS = DH / 32;      // MFMA k-steps over the head dimension
     constexpr int DT = DH / 16;      // 16-wide output (dv) tiles
     constexpr int NP = DH / 32;      // 16-byte pieces per thread per staged operand (64*DH*2 B / 4 KB)
-    __shared__ __attribute__((aligned(16))) bf16 Ks[2][AF_KC * DH];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[2][DH * AF_KC];
+    constexpr int KLD = DH + AF_PAD;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[2][AF_KC * KLD];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[2][DH * AF_VLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int pi = tid + 256 * u;
-            *reinterpret_cast<u32x4*>(&Ks[buf][pi * 8]) = rk[u];      // same linear order as the global chunk
-            *reinterpret_cast<u32x4*>(&Vs[buf][pi * 8]) = rv[u];
+            *reinterpret_cast<u32x4*>(&Ks[buf][(pi / (DH / 8)) * KLD + (pi % (DH / 8)) * 8]) = rk[u];
+            *reinterpret_cast<u32x4*>(&Vs[buf][(pi >> 3) * AF_VLD + (pi & 7) * 8]) = rv[u];
         }
     };
 
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
         for (int kt = 0; kt < 4; ++kt) {
             bf16x8 kf[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(Kc + (16 * kt + c) * DH + 32 * s + 8 * g);
+            for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(Kc + (16 * kt + c) * KLD + 32 * s + 8 * g);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 sacc[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const bf16* vrow = Vc + (16 * d + c) * AF_KC + 32 * ks + 4 * g;
+                const bf16* vrow = Vc + (16 * d + c) * AF_VLD + 32 * ks + 4 * g;
                 const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
                 const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, (u32x4){lo.x, lo.y, hi.x, hi.y});
@@ -217,8 +220,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                                int H, int Tn, float scale, DropSpec drop) {
     constexpr int KS = DH / 32, DT = DH / 16, NP = DH / 32;
-    __shared__ __attribute__((aligned(16))) bf16 Ks[2][AF_KC * DH];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[2][DH * AF_KC];
+    constexpr int KLD = DH + AF_PAD;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[2][AF_KC * KLD];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[2][DH * AF_VLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
     {                                                                                                             \
         _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                          \
             const int pi = tid + 256 * u;                                                                         \
-            *reinterpret_cast<u32x4*>(&Ks[buf][pi * 8]) = rk[u];                                                  \
-            *reinterpret_cast<u32x4*>(&Vs[buf][pi * 8]) = rv[u];                                                  \
+            *reinterpret_cast<u32x4*>(&Ks[buf][(pi / (DH / 8)) * KLD + (pi % (DH / 8)) * 8]) = rk[u];            \
+            *reinterpret_cast<u32x4*>(&Vs[buf][(pi >> 3) * AF_VLD + (pi & 7) * 8]) = rv[u];                       \
         }                                                                                                         \
     }
     DQ_GLOAD(0);
@@ -294,8 +298,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
                 bf16x8 kf[KS], vf[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    kf[s] = *reinterpret_cast<const bf16x8*>(Kc + (16 * kt + c) * DH + 32 * s + 8 * g);
-                    vf[s] = trfrag(Vc, AF_KC, 32 * s + 8 * g, 32 * s + 8 * g + 4, 16 * kt, lane);    // V[key c][dv 32s+8g..+7]
+                    kf[s] = *reinterpret_cast<const bf16x8*>(Kc + (16 * kt + c) * KLD + 32 * s + 8 * g);
+                    vf[s] = trfrag(Vc, AF_VLD, 32 * s + 8 * g, 32 * s + 8 * g + 4, 16 * kt, lane);    // V[key c][dv 32s+8g..+7]
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const bf16x8 ktf = trfrag(Kc, DH, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
+                const bf16x8 ktf = trfrag(Kc, KLD, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsb[t][ks], acc[d][t], 0, 0, 0);
             }
@@ -360,8 +364,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __re
                                                                 const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                                 int H, int Tn, float scale, DropSpec drop) {
     constexpr int KS = DH / 32, DT = DH / 16, NP = DH / 32;
-    __shared__ __attribute__((aligned(16))) bf16 Qs[2][AF_KC * DH];
-    __shared__ __attribute__((aligned(16))) bf16 Ds[2][AF_KC * DH];
+    constexpr int KLD = DH + AF_PAD;
+    __shared__ __attribute__((aligned(16))) bf16 Qs[2][AF_KC * KLD];
+    __shared__ __attribute__((aligned(16))) bf16 Ds[2][AF_KC * KLD];
     __shared__ float Ls[2][AF_KC], Dl[2][AF_KC];
     __shared__ uint32_t Rk[2][AF_KC];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -416,8 +421,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __re
     {                                                                                                             \
         _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                          \
             const int pi = tid + 256 * u;                                                                         \
-            *reinterpret_cast<u32x4*>(&Qs[buf][pi * 8]) = rq[u];                                                  \
-            *reinterpret_cast<u32x4*>(&Ds[buf][pi * 8]) = rd[u];                                                  \
+            *reinterpret_cast<u32x4*>(&Qs[buf][(pi / (DH / 8)) * KLD + (pi % (DH / 8)) * 8]) = rq[u];            \
+            *reinterpret_cast<u32x4*>(&Ds[buf][(pi / (DH / 8)) * KLD + (pi % (DH / 8)) * 8]) = rd[u];            \
         }                                                                                                         \
         if (tid < 64) Ls[buf][tid] = rl;                                                                          \
         else if (tid < 128) Dl[buf][tid - 64] = rl;                                                               \
@@ -443,8 +448,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __re
                 bf16x8 qfr[KS], dfr[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    qfr[s] = *reinterpret_cast<const bf16x8*>(Qc + (16 * qt + c) * DH + 32 * s + 8 * g);
-                    dfr[s] = *reinterpret_cast<const bf16x8*>(Dc + (16 * qt + c) * DH + 32 * s + 8 * g);
+                    qfr[s] = *reinterpret_cast<const bf16x8*>(Qc + (16 * qt + c) * KLD + 32 * s + 8 * g);
+                    dfr[s] = *reinterpret_cast<const bf16x8*>(Dc + (16 * qt + c) * KLD + 32 * s + 8 * g);
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -486,8 +491,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __re
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const bf16x8 dtf = trfrag(Dc, DH, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
-                const bf16x8 qtf = trfrag(Qc, DH, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
+                const bf16x8 dtf = trfrag(Dc, KLD, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
+                const bf16x8 qtf = trfrag(Qc, KLD, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     adv[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtf, pdb[t][ks], adv[d][t], 0, 0, 0);

@@ -192,31 +192,44 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
     const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
     const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
     const int rows = DW_TT + k - 1;
-    // ---- stage: thread -> chunk (tid&15) of 8 channels, rows (tid>>4) + 16*it
+    // ---- stage: thread -> chunk (tid&15) of 8 channels, rows (tid>>4) + 16*it.  All global loads of the
+    // tile are issued before the first use (rows <= 94 -> at most 6 row groups per thread).
     {
         const int ch = c0 + (tid & 15) * 8;
-        for (int r = tid >> 4; r < rows; r += 16) {
+        constexpr int NIT = (DW_TT + DW_MAXK - 1 + 15) / 16;
+        float v[NIT][8], gl[NIT][8];
+        bool ok[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = (tid >> 4) + 16 * it;
             const int tin = t0 - padl + r;
-            float v[8];
-            if (tin >= 0 && tin < Tn && ch < C) {
+            ok[it] = r < rows && tin >= 0 && tin < Tn && ch < C;
+            if (ok[it]) {
                 const T* p = x + ((size_t)b * Tn + tin) * Cin + ch;
-                load8(p, v);
-                if (inop == DWIN_SWISH) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
-                } else if (inop == DWIN_GLU) {
-                    float g[8];
-                    load8(p + C, g);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(g[e]);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                load8(p, v[it]);
+                if (inop == DWIN_GLU) load8(p + C, gl[it]);
             }
-            float* dst = tile + r * DW_CT + (tid & 15) * 8;
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            if (r < rows) {
+                if (ok[it]) {
+                    if (inop == DWIN_SWISH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[it][e] = swishf_(v[it][e]);
+                    } else if (inop == DWIN_GLU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[it][e] *= sigmoidf_(gl[it][e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+                }
+                float* dst = tile + r * DW_CT + (tid & 15) * 8;
+                *reinterpret_cast<float4*>(dst) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+            }
         }
     }
     __syncthreads();
@@ -337,45 +350,75 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[q][e] = 0.f;
-    for (int item = blockIdx.y; item < B * ntt; item += gridDim.y) {
+    // staging registers: x tile rows (tid>>4)+16*it (it < NX), dy tile rows (tid>>4)+16*it (it < 2); the next item's
+    // loads are issued before the current item's compute and written to LDS after it (one LDS image, two barriers/item)
+    constexpr int NX = (DWG_TT + DW_MAXK - 1 + 15) / 16;
+    float xv[NX][8], xg[NX][8], dv[2][8];
+    bool xok[NX], dok[2];
+    const int ch8 = c0 + (tid & 15) * 8;
+    auto gload = [&](int item) {
         const int b = item / ntt, t0 = (item % ntt) * DWG_TT;
-        const int ch8 = c0 + (tid & 15) * 8;
-        for (int r = tid >> 4; r < rows; r += 16) {
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int r = (tid >> 4) + 16 * it;
             const int tin = t0 - padl + r;
-            float v[8];
-            if (tin >= 0 && tin < Tn && ch8 < C) {
+            xok[it] = r < rows && tin >= 0 && tin < Tn && ch8 < C;
+            if (xok[it]) {
                 const T* p = x + ((size_t)b * Tn + tin) * Cin + ch8;
-                load8(p, v);
-                if (inop == DWIN_SWISH) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
-                } else if (inop == DWIN_GLU) {
-                    float g[8];
-                    load8(p + C, g);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(g[e]);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                load8(p, xv[it]);
+                if (inop == DWIN_GLU) load8(p + C, xg[it]);
             }
-            float* dst = xt + r * DW_CT + (tid & 15) * 8;
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
-        for (int r = tid >> 4; r < DWG_TT; r += 16) {
-            const int t = t0 + r;
-            float v[8];
-            if (t < Tn && ch8 < C) load8(dy + ((size_t)b * Tn + t) * C + ch8, v);
-            else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int it = 0; it < 2; ++it) {
+            const int t = t0 + (tid >> 4) + 16 * it;
+            dok[it] = t < Tn && ch8 < C;
+            if (dok[it]) load8(dy + ((size_t)b * Tn + t) * C + ch8, dv[it]);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            if (r < rows) {
+                if (xok[it]) {
+                    if (inop == DWIN_SWISH) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xv[it][e] = swishf_(xv[it][e]);
+                    } else if (inop == DWIN_GLU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xv[it][e] *= sigmoidf_(xg[it][e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[it][e] = 0.f;
+                }
+                float* dst = xt + r * DW_CT + (tid & 15) * 8;
+                *reinterpret_cast<float4*>(dst) = make_float4(xv[it][0], xv[it][1], xv[it][2], xv[it][3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(xv[it][4], xv[it][5], xv[it][6], xv[it][7]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = (tid >> 4) + 16 * it;
+            if (!dok[it]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[it][e] = 0.f;
             }
             float* dst = dt_ + r * DW_CT + (tid & 15) * 8;
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            *reinterpret_cast<float4*>(dst) = make_float4(dv[it][0], dv[it][1], dv[it][2], dv[it][3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(dv[it][4], dv[it][5], dv[it][6], dv[it][7]);
         }
+    };
+    const int nitems = B * ntt;
+    int item = blockIdx.y;
+    if (item < nitems) gload(item);
+    for (; item < nitems; item += gridDim.y) {
+        __syncthreads();                       // previous item's compute is done with the LDS image
+        lstore();
         __syncthreads();
+        const int nxt = item + gridDim.y;
+        if (nxt < nitems) gload(nxt);          // in flight during the compute below
         for (int t = 0; t < DWG_TT; ++t) {
             const float4 d = *reinterpret_cast<const float4*>(dt_ + t * DW_CT + cl * 4);
             if (tl == 0) { accb[0] += d.x; accb[1] += d.y; accb[2] += d.z; accb[3] += d.w; }
@@ -383,12 +426,11 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
             for (int q = 0; q < 4; ++q) {
                 const int j = tl + 8 * q;
                 if (j < k) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xt + (t + j) * DW_CT + cl * 4);
-                    acc[q][0] += d.x * xv.x; acc[q][1] += d.y * xv.y; acc[q][2] += d.z * xv.z; acc[q][3] += d.w * xv.w;
+                    const float4 xq = *reinterpret_cast<const float4*>(xt + (t + j) * DW_CT + cl * 4);
+                    acc[q][0] += d.x * xq.x; acc[q][1] += d.y * xq.y; acc[q][2] += d.z * xq.z; acc[q][3] += d.w * xq.w;
                 }
             }
         }
-        __syncthreads();
     }
     const int ch = c0 + cl * 4;
     if (ch < C) {

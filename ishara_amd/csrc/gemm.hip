@@ -621,6 +621,9 @@ static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int 
     }
 }
 
+// name of the kernel launch_gemm_nt / launch_gemm_tn will pick (profiler keys = rocprof kernel names)
+const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int K, int ldb);
+const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb);
 int g_force_regstage = 0;   // 0: LDS-DMA 64x128 kernel whenever eligible (default); 1: always the register-staged 128x128 kernel
 int g_dbg_tn = 0;           // ablation bits for the TN kernel: 1 skip MFMA, 2 skip LDS stores, 4 skip global loads
 
@@ -803,17 +806,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TA* __restrict__ A, 
 // operand transform, M % 64 == 0, Ka % 128 == 0, Nb % 128 == 0).
 // Both operands are [m][feature] row-major in HBM and the MFMA reduction index is m, i.e. the
 // fragments are COLUMNS of the stored tiles.  Instead of transposing through registers, the
-// 64-row x 128-column tiles (256-byte rows) are copied as they are by global_load_lds_dwordx4
-// into a 4-deep LDS ring (three tiles in flight), and each fragment is fetched with two
+// 32-row x 128-column tiles (256-byte rows) are copied as they are by global_load_lds_dwordx4
+// into a 4-deep LDS ring (three tiles in flight, two workgroups per CU), and each fragment is fetched with two
 // ds_read_b64_tr_b16 (a 4-row x 16-column block delivered column-major).  The 32-byte column
 // blocks of a row are XOR-swizzled with f(row) = (row&3) | ((row>>3)&1)<<2 — applied on the
 // SOURCE address of the DMA and on the read — so the 8 rows a 32-lane half reads land in 8
 // different 32-byte bank groups (conflict-free).  The bias gradient (column sums of dY) is
-// accumulated from the B fragments already in registers.
+// accumulated from the B fragments already in registers.  M is split over workgroups; each writes
+// its 128x128 fp32 partial to a slab with coalesced 16-byte stores (an all-at-once fp32-atomic
+// epilogue measured 40 us for 32 MB, the chip-wide atomic rate) and reduce_slabs_kernel sums them.
 // ---------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
-#define TR_STAGE 32768          // A 64 x 256 B + B 64 x 256 B
+#define TR_STAGE 16384          // A 32 rows x 256 B + B 32 rows x 256 B
+#define TR_ROWS 32
 #define TR_NSTAGE 4
 
 DEVI int tr_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -822,14 +828,14 @@ DEVI void tr_issue(const bf16* __restrict__ A, const bf16* __restrict__ B, int K
                    char* stage, int wid, int lane) {
     const int r = lane >> 4, sp = lane & 15;            // row within a 4-row piece, physical 16-byte slot
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                        // 16 pieces per operand; wave takes wid, wid+4, ...
+    for (int u = 0; u < 2; ++u) {                        // 8 four-row pieces per operand; wave takes wid, wid+4
         const int pc = wid + 4 * u;
         const int row = 4 * pc + r;
         const int col = (((sp >> 1) ^ tr_f(row)) << 4) + ((sp & 1) << 3);     // logical column of physical slot sp
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)(mrow0 + row) * Ka + k0 + col),
                                          (__attribute__((address_space(3))) void*)(stage + pc * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + (size_t)(mrow0 + row) * Nb + n0 + col),
-                                         (__attribute__((address_space(3))) void*)(stage + 16384 + pc * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(stage + 8192 + pc * 1024), 16, 0, 0);
     }
 }
 
@@ -844,20 +850,27 @@ DEVI bf16x8 tr_frag(const char* tile, int lb, int s, int lane) {
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
-                                                         float* __restrict__ slab, float* __restrict__ bias_slab,
-                                                         int M, int Ka, int Nb, int rows_per_split) {
+                                                         float* __restrict__ out, float* __restrict__ dbias,
+                                                         int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, int dbg) {
     __shared__ __attribute__((aligned(16))) char smem[TR_NSTAGE * TR_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
     const int nNt = Nb >> 7;
-    const int kt = blockIdx.x / nNt, nt = blockIdx.x % nNt;
+    // XCD-aware mapping (blocks b, b+8 share an XCD / L2): the `tiles` output tiles of one M-split read the same
+    // A and dY rows, so they are dealt to ONE XCD back to back; consecutive splits go to different XCDs.
+    int tile, split;
+    {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        if ((nsplits & 7) == 0) { split = (j / tiles) * 8 + xcd; tile = j % tiles; }
+        else { split = id / tiles; tile = id % tiles; }
+    }
+    const int kt = tile / nNt, nt = tile % nNt;
     const int k0 = kt << 7, n0 = nt << 7;
-    const int split = blockIdx.y;
     const int m_beg = split * rows_per_split;
     const int m_end = min(M, m_beg + rows_per_split);
-    const int nmc = (m_end - m_beg) >> 6;                 // whole 64-row tiles (launcher guarantees)
-    const bool want_bias = (bias_slab != nullptr) && (kt == 0) && (wr == 0);
+    const int nmc = max(0, m_end - m_beg) / TR_ROWS;      // whole 32-row tiles (launcher guarantees)
+    const bool want_bias = (dbias != nullptr) && (kt == 0) && (wr == 0);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -868,25 +881,25 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(const bf16* __restrict_
 
 #pragma unroll
     for (int st = 0; st < TR_NSTAGE - 1; ++st)
-        if (st < nmc) tr_issue(A, B, Ka, Nb, k0, n0, m_beg + st * 64, smem + st * TR_STAGE, wid, lane);
+        if (st < nmc && !(dbg & 4)) tr_issue(A, B, Ka, Nb, k0, n0, m_beg + st * TR_ROWS, smem + st * TR_STAGE, wid, lane);
     for (int mc = 0; mc < nmc; ++mc) {
-        // 8 DMA per wave per tile; tiles mc+1, mc+2 may stay in flight
+        // 4 DMA per wave per tile; tiles mc+1, mc+2 may stay in flight
         const int ahead = min(nmc - 1 - mc, TR_NSTAGE - 2);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (mc + TR_NSTAGE - 1 < nmc)
-            tr_issue(A, B, Ka, Nb, k0, n0, m_beg + (mc + TR_NSTAGE - 1) * 64, smem + ((mc + TR_NSTAGE - 1) % TR_NSTAGE) * TR_STAGE, wid, lane);
+        if (mc + TR_NSTAGE - 1 < nmc && !(dbg & 4))
+            tr_issue(A, B, Ka, Nb, k0, n0, m_beg + (mc + TR_NSTAGE - 1) * TR_ROWS, smem + ((mc + TR_NSTAGE - 1) % TR_NSTAGE) * TR_STAGE, wid, lane);
         const char* sa = smem + (mc % TR_NSTAGE) * TR_STAGE;
-        const char* sb = sa + 16384;
+        const char* sb = sa + 8192;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 1; ++s) {
             bf16x8 a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = tr_frag(sa, wr * 4 + i, s, lane);
+            for (int i = 0; i < 4; ++i) a[i] = (dbg & 2) ? bf16x8{} : tr_frag(sa, wr * 4 + i, s, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = tr_frag(sb, wc * 4 + j, s, lane);
+            for (int j = 0; j < 4; ++j) b[j] = (dbg & 2) ? bf16x8{} : tr_frag(sb, wc * 4 + j, s, lane);
             if (want_bias) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -896,32 +909,48 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(const bf16* __restrict_
                     csum[j] += t;
                 }
             }
+            if (!(dbg & 1)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][0][0] += (float)a[i][0] + (float)b[i][0];
+            }
         }
     }
 
-    float* out = slab + (size_t)split * Ka * Nb;
+    // ---- write this split's 128x128 partial to its fp32 slab: each wave transposes its 64x64 accumulator block through
+    // a private LDS stage (two 32-row passes) so that every store instruction writes 4 rows x 256 contiguous bytes
+    __syncthreads();                       // the ring is free
+    if (dbg & 8) { if (acc[0][0][0] == 123.f) out[0] = acc[1][1][1]; return; }
+    {
+        constexpr int SLD = 68;
+        float* stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kk = k0 + wr * 64 + 16 * i + 4 * (lane >> 4) + r;
-                const int nn = n0 + wc * 64 + 16 * j + (lane & 15);
-                out[(size_t)kk * Nb + nn] = acc[i][j][r];
-            }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stage[(16 * ii + 4 * (lane >> 4) + r) * SLD + 16 * j + (lane & 15)] = acc[2 * p + ii][j][r];
+            float* orow = out + (size_t)split * Ka * Nb + (size_t)(k0 + wr * 64 + 32 * p + (lane >> 4)) * Nb + n0 + wc * 64 + (lane & 15) * 4;
+#pragma unroll
+            for (int it = 0; it < 8; ++it)       // one instruction = 4 rows x 256 contiguous bytes
+                *reinterpret_cast<float4*>(orow + (size_t)(4 * it) * Nb) = *reinterpret_cast<const float4*>(stage + ((lane >> 4) + 4 * it) * SLD + (lane & 15) * 4);
+        }
+    }
     if (want_bias) {   // lane (g, c) holds the sum over rows 8g..8g+7 (mod 32) of column 16j + c: fold the 4 row groups
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float t = csum[j];
             t += __shfl_xor(t, 16, 64);
             t += __shfl_xor(t, 32, 64);
-            if (lane < 16) bias_slab[(size_t)split * Nb + n0 + wc * 64 + 16 * j + lane] = t;
+            if (lane < 16) dbias[(size_t)split * Nb + n0 + wc * 64 + 16 * j + lane] = t;
         }
     }
 }
@@ -934,13 +963,13 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     const int per = (splits + gridDim.y - 1) / gridDim.y;
     const int s0 = blockIdx.y * per, s1 = min(splits, s0 + per);
     if (i4 + 4 <= n && (stride & 3) == 0) {
-        float4 acc[4];
+        float4 acc[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         int sidx = s0;
-        for (; sidx + 4 <= s1; sidx += 4) {
+        for (; sidx + 8 <= s1; sidx += 8) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)(sidx + u) * stride + i4);
                 acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
             }
@@ -949,10 +978,16 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
             const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)sidx * stride + i4);
             acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
         }
-        atomicAdd(out + i4, (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x));
-        atomicAdd(out + i4 + 1, (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y));
-        atomicAdd(out + i4 + 2, (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z));
-        atomicAdd(out + i4 + 3, (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w));
+#pragma unroll
+        for (int u = 1; u < 8; ++u) { acc[0].x += acc[u].x; acc[0].y += acc[u].y; acc[0].z += acc[u].z; acc[0].w += acc[u].w; }
+        if (gridDim.y == 1) {
+            float4 o = *reinterpret_cast<const float4*>(out + i4);
+            o.x += acc[0].x; o.y += acc[0].y; o.z += acc[0].z; o.w += acc[0].w;
+            *reinterpret_cast<float4*>(out + i4) = o;
+        } else {
+            atomicAdd(out + i4, acc[0].x); atomicAdd(out + i4 + 1, acc[0].y);
+            atomicAdd(out + i4 + 2, acc[0].z); atomicAdd(out + i4 + 3, acc[0].w);
+        }
     } else {
         for (int e = 0; e < 4 && i4 + e < n; ++e) {
             float acc = 0.f;
@@ -964,8 +999,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s) {
     const int gx = (n + 1023) / 1024;
-    int gy = max(1, min(splits / 4, 2048 / max(gx, 1)));
-    if (gy > 16) gy = 16;
+    int gy = 1;                                            // split groups: enough workgroups to fill the chip
+    while (gx * gy < 512 && gy * 16 <= splits) gy *= 2;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, gy), dim3(256), 0, s, slab, out, n, splits, stride);
 }
 
@@ -983,7 +1018,7 @@ static void tn_plan(int M, int Ka, int Nb, int dtM, int& splits, int& rows_per_s
 size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM) {
     int splits, rps;
     tn_plan(M, Ka, Nb, dtM, splits, rps);
-    if (splits < 256) splits = 256;        // the transposed-read kernel plans <= 256 splits
+    if (splits < 512) splits = 512;        // the transposed-read kernel plans <= 512 splits
     return (size_t)splits * ((size_t)Ka * Nb + Nb);
 }
 
@@ -991,13 +1026,13 @@ int g_force_tn_regstage = 0;   // tests: force the register-transposing TN kerne
 
 static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s) {
     const int tiles = (Ka / 128) * (Nb / 128);
-    int want = max(1, 256 / tiles);                       // one 128 KB-LDS workgroup per CU
-    const int maxs = max(1, M / 256);                     // at least 4 tiles per split
+    int want = max(1, 512 / tiles);                       // two 64 KB-LDS workgroups per CU
+    const int maxs = max(1, M / 256);                     // at least 8 tiles per split
     if (want > maxs) want = maxs;
-    const int rps = ((M + want - 1) / want + 63) / 64 * 64;
+    const int rps = ((M + want - 1) / want + TR_ROWS - 1) / TR_ROWS * TR_ROWS;
     const int splits = (M + rps - 1) / rps;
     float* bias_slab = dbias ? slab + (size_t)splits * Ka * Nb : nullptr;
-    hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles, splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps);
+    hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn);
     launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
     if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1067,4 +1102,18 @@ int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt,
     if (dtM == DT_BF16) hipLaunchKernelGGL(make_shadow_kernel<bf16>, grid, dim3(256), 0, s, W, K, N, (bf16*)Wt, ldt, (bf16*)Wn, ldn);
     else hipLaunchKernelGGL(make_shadow_kernel<float>, grid, dim3(256), 0, s, W, K, N, (float*)Wt, ldt, (float*)Wn, ldn);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int K, int ldb) {
+    const int bk = dtM == DT_BF16 ? 32 : 16;
+    const bool glds = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0 && !g_force_regstage;
+    if (glds) return dtM == DT_F32 ? "gemm_nt_glds_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_glds_kernel<bf16,f32>" : "gemm_nt_glds_kernel<bf16,bf16>");
+    if (dtA == DT_F32 && dtM == DT_BF16) return "gemm_nt_kernel<f32,bf16,bf16>";
+    if (dtM == DT_F32) return "gemm_nt_kernel<f32,f32,f32>";
+    return dtC == DT_F32 ? "gemm_nt_kernel<bf16,bf16,f32>" : "gemm_nt_kernel<bf16,bf16,bf16>";
+}
+const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb) {
+    if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && opA == OP_NONE && opB == OP_NONE && M % 64 == 0 && Ka % 128 == 0 && Nb % 128 == 0 &&
+        M >= 256 && !g_force_tn_regstage) return "gemm_tn_tr_kernel";
+    return dtM == DT_F32 ? "gemm_tn_kernel<f32,f32,f32>" : (dtA == DT_F32 ? "gemm_tn_kernel<f32,bf16,bf16>" : (dtB == DT_F32 ? "gemm_tn_kernel<bf16,f32,bf16>" : "gemm_tn_kernel<bf16,bf16,bf16>"));
 }

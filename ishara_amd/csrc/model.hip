@@ -455,17 +455,17 @@ extern "C" int ishara_sync_weights(ishara_model* m, ishara_stream st) {
 static int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea) {
     if (w.b >= 0) ea.bias = m->P(w.b);
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtC) * (1 + (ea.resid ? 1 : 0) + (ea.pre_out ? 1 : 0)) + (double)w.K * w.N * dt_size(m->dt);
-    CKP(m, "gemm_nt", by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, dtC, aop, A, m->ws + w.wt, Cc, M, w.N, w.K, w.ldt, oa, ea, m->s));
+    CKP(m, gemm_nt_kernel_name(dtA, m->dt, dtC, aop, A, w.K, w.ldt), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, dtC, aop, A, m->ws + w.wt, Cc, M, w.N, w.K, w.ldt, oa, ea, m->s));
     return 0;
 }
 static int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea) {
     const double by = (double)M * w.N * dt_size(dtA) + (double)M * w.K * dt_size(m->dt) * (1 + (ea.resid ? 1 : 0) + (ea.aux ? 1 : 0)) + (double)w.K * w.N * dt_size(m->dt);
-    CKP(m, "gemm_nt", by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
+    CKP(m, gemm_nt_kernel_name(dtA, m->dt, m->dt, aop, dY, w.N, w.ldn), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
     return 0;
 }
 static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
-    CKP(m, "gemm_tn", by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s));
+    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s));
     return 0;
 }
 
@@ -860,7 +860,7 @@ extern "C" int ishara_op_dense_bwd(int32_t dt, const void* x, const float* Wm, c
     HIP_CHECK_RET(hipMemsetAsync(sc, 0, slab, s));
     CK(launch_make_shadow(dt, Wm, K, N, sc + wt, ldt, sc + wn, ldn, s));
     OpArgs no; EpiArgs ea;
-    CK(launch_gemm_nt(dt, dt, dt, OP_NONE, dy, sc + wn, dx, M, K, N, ldn, no, ea, s));
+    if (dx) CK(launch_gemm_nt(dt, dt, dt, OP_NONE, dy, sc + wn, dx, M, K, N, ldn, no, ea, s));
     return launch_gemm_tn(dt, dt, dt, OP_NONE, OP_NONE, x, dy, dW, db, (float*)(sc + slab), M, K, N, no, no, s);
 }
 extern "C" int ishara_op_layernorm_fwd(int32_t dt, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int32_t M, int32_t C, ishara_stream s) {

@@ -36,26 +36,25 @@ for (M, K, N) in shapes:
     gb = (M * K * 2 + M * N * 2) / 1e9
     print(f"M{M} K{K} N{N}: " + "  ".join(f"{k}={min(v):.0f}us" for k, v in res.items()) + f"   [{gb / (min(res['glds']) * 1e-6) / 1e3:.2f} TB/s, includes shadow build+memset]")
 
-print("---- TN (wgrad): dW = x^T dy ; dx path excluded by timing dense_bwd minus its NT part is not possible, so time bwd as a whole")
-for (M, K, N) in [(98304, 256, 512), (98304, 512, 256)]:
+print("---- TN (wgrad only: dW = x^T dy, + slab reduce + shadow build)")
+for (M, K, N) in [(98304, 256, 512), (98304, 512, 256), (98304, 256, 768)]:
     x = torch.randn(M, K, device="cuda").bfloat16()
     dy = torch.randn(M, N, device="cuda").bfloat16()
     W = torch.randn(K, N, device="cuda") / K ** 0.5
-    dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
     dW = torch.zeros(K, N, device="cuda"); db = torch.zeros(N, device="cuda")
     sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
     scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
     res = {}
     for rnd in range(3):
-        for name, flag in {"full": 0, "tn-regstage": 2}.items():
+        for name, flag in {"tr": 0, "tr-nomma": (1 << 8), "tr-nofrag": (2 << 8), "tr-noload": (4 << 8), "tr-nothing": (7 << 8), "regstage-tn": 2}.items():
             lib.ishara_debug_force_regstage(flag)
             for _ in range(2):
-                lib.ishara_op_dense_bwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, st())
+                lib.ishara_op_dense_bwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), None, _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, st())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                lib.ishara_op_dense_bwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, st())
+                lib.ishara_op_dense_bwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(dy), None, _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, st())
             e1.record(); torch.cuda.synchronize()
             res.setdefault(name, []).append(e0.elapsed_time(e1) / 10 * 1e3)
     lib.ishara_debug_force_regstage(0)
-    print(f"bwd M{M} K{K} N{N} (dgrad NT + wgrad TN + reduce + shadows): " + "  ".join(f"{k}={min(v):.0f}us" for k, v in res.items()))
+    print(f"wgrad M{M} K{K} N{N}: " + "  ".join(f"{k}={min(v):.0f}us" for k, v in res.items()))
