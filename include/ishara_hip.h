@@ -108,7 +108,8 @@ int ishara_ctc_loss(const float* logits, const int64_t* labels, int32_t B, int32
 int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, int32_t cols, float rate,
                         float* out, ishara_stream s);
 
-/* tests: 1 = always use the register-staged GEMM kernels (the LDS-DMA kernels are the default) */
+/* tests/ablation: bit0 register-staged NT GEMM, bit1 register-transposing TN GEMM, bit2 LDS-tiled depthwise conv
+ * (defaults: LDS-DMA NT, transposed-read TN, register-window depthwise conv); bits 4-11 ablation switches */
 int ishara_debug_force_regstage(int32_t on);
 
 /* ---- single-operator entry points (parity tests of the individual kernels) ------------ */
@@ -128,9 +129,11 @@ int ishara_op_layernorm_bwd(int32_t dt, const void* dy, const void* x, const flo
 int ishara_op_dwconv_fwd(int32_t dt, int32_t inop, const void* x, const float* w, const float* bias, void* y,
                          float* ssum, float* ssq, int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl,
                          ishara_stream s);
+int64_t ishara_op_dwconv_scratch_bytes(int32_t C, int32_t k);
+/* scratch: ishara_op_dwconv_scratch_bytes(C,k) bytes, or NULL (atomic weight-grad path) */
 int ishara_op_dwconv_bwd(int32_t dt, int32_t inop, const void* dy, const void* x, const float* w, void* dx,
-                         float* dw, float* dbias, int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl,
-                         ishara_stream s);
+                         float* dw, float* dbias, void* scratch, int32_t B, int32_t T, int32_t C, int32_t k,
+                         int32_t padl, ishara_stream s);
 /* attention on packed qkv [B*T, 3*H*dh] (head-major packing): o [B*T, H*dh]; scratch holds q,k,vt,lse,delta */
 int64_t ishara_op_attn_scratch_bytes(int32_t B, int32_t H, int32_t T, int32_t dh);
 int ishara_op_attn_fwd(int32_t dt, const void* qkv, void* o, int32_t B, int32_t H, int32_t T, int32_t dh,

@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
+void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s);
 
 static inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
@@ -315,6 +316,294 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Register-window variants for the kernel sizes the model uses (K in {3,5,11,15}): a thread
+// owns 4 channels x DWR_SEG consecutive time steps of one sample, keeps the last K transformed
+// inputs and the K taps in registers (slot indices are compile-time through a K-unrolled body),
+// so every input element is loaded and activated once, there is no LDS tile and no barrier.
+// -------------------------------------------------------------------------------------
+#define DWR_SEG 32
+
+// raw 4-channel load (value v, GLU gate g) and the input transform, kept separate so that a K-group's loads can all be
+// issued before the first one is consumed
+template <typename T>
+DEVI void dw_raw(const T* __restrict__ x, int b, int tin, int Tn, int C, int Cin, int ch, int inop, float (&v)[4], float (&g)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    g[0] = g[1] = g[2] = g[3] = 0.f;
+    if (tin < 0 || tin >= Tn) return;
+    const T* p = x + ((size_t)b * Tn + tin) * Cin + ch;
+    load4g(p, v);
+    if (inop == DWIN_GLU) load4g(p + C, g);
+}
+DEVI void dw_xform(int inop, float (&v)[4], const float (&g)[4]) {
+    if (inop == DWIN_SWISH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = swishf_(v[e]);
+    } else if (inop == DWIN_GLU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= sigmoidf_(g[e]);
+    }
+}
+template <typename T>
+DEVI void dw_load_in(const T* __restrict__ x, int b, int tin, int Tn, int C, int Cin, int ch, int inop, float (&v)[4]) {
+    float g[4];
+    dw_raw(x, b, tin, Tn, C, Cin, ch, inop, v, g);
+    dw_xform(inop, v, g);
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_reg_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         T* __restrict__ y, const T* __restrict__ aux,
+                                                         float* __restrict__ ssum, float* __restrict__ ssq,
+                                                         int Tn, int C, int padl, int inop, int outop, int flip) {
+    const int cg = C >> 2;
+    const int nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nseg * cg) return;
+    const int c4 = i % cg, seg = i / cg, b = blockIdx.y;
+    const int ch = c4 * 4;
+    const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
+    float wr[K][4], win[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) load4(w + (size_t)(flip ? (K - 1 - j) : j) * C + ch, wr[j]);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) load4(bias + ch, bv);
+    const int t0 = seg * DWR_SEG, tend = min(Tn, t0 + DWR_SEG);
+    // slots 0..K-2 hold inputs t0-padl .. t0-padl+K-2
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) dw_load_in(x, b, t0 - padl + j, Tn, C, Cin, ch, inop, win[j]);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tb = t0; tb < tend; tb += K) {
+        float nv[K][4], ng[K][4];                // the K new input rows of this group: all loads in flight together
+#pragma unroll
+        for (int u = 0; u < K; ++u) dw_raw(x, b, (tb + u < tend) ? tb + u - padl + K - 1 : -1, Tn, C, Cin, ch, inop, nv[u], ng[u]);
+#pragma unroll
+        for (int u = 0; u < K; ++u) {            // output t = tb + u uses slots (u + j) % K ; the new input lands in slot (u + K - 1) % K
+            const int t = tb + u;
+            if (t < tend) {
+                dw_xform(inop, nv[u], ng[u]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) win[(u + K - 1) % K][e] = nv[u][e];
+                float o[4] = {bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += wr[j][e] * win[(u + j) % K][e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[e] += o[e]; s2[e] += o[e] * o[e]; }
+                const size_t row = (size_t)b * Tn + t;
+                if (outop == OUT_NONE) {
+                    store4(y + row * C + ch, o);
+                } else if (outop == OUT_DSWISH) {
+                    float a[4];
+                    load4g(aux + row * C + ch, a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= dswishf_(a[e]);
+                    store4(y + row * C + ch, o);
+                } else {
+                    float a1[4], a2[4], o2[4];
+                    load4g(aux + row * 2 * C + ch, a1);
+                    load4g(aux + row * 2 * C + C + ch, a2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sg = sigmoidf_(a2[e]);
+                        o2[e] = o[e] * a1[e] * sg * (1.f - sg);
+                        o[e] *= sg;
+                    }
+                    store4(y + row * 2 * C + ch, o);
+                    store4(y + row * 2 * C + C + ch, o2);
+                }
+            }
+        }
+    }
+    if (ssum) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(ssum + (size_t)b * C + ch + e, s1[e]);
+            if (ssq) atomicAdd(ssq + (size_t)b * C + ch + e, s2[e]);
+        }
+    }
+}
+
+// weight gradient: thread = 4 channels; a workgroup = 256/cg (sample, segment) lanes that each loop over many items with
+// dw[K][4] (+ dbias) in registers; lanes are combined through LDS and each workgroup writes ONE partial row
+// part[blockIdx.x][K+1][C] (summed by reduce_slabs: no same-address atomics).
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_reg_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part,
+                                                               int B, int Tn, int C, int padl, int inop) {
+    extern __shared__ float red[];           // [(K+1)*C] block accumulator
+    const int cg = C >> 2;
+    const int lanes = 256 / cg;              // item lanes per workgroup (cg <= 256)
+    const int c4 = threadIdx.x % cg, il = threadIdx.x / cg;
+    const int ch = c4 * 4;
+    const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
+    const int nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
+    const int nitems = B * nseg;
+    for (int q = threadIdx.x; q < (K + 1) * C; q += 256) red[q] = 0.f;
+    __syncthreads();
+    float acc[K][4], accb[4] = {0.f, 0.f, 0.f, 0.f}, win[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f; }
+    if (il < lanes) {
+        for (int item = blockIdx.x * lanes + il; item < nitems; item += gridDim.x * lanes) {
+            const int b = item / nseg, t0 = (item % nseg) * DWR_SEG, tend = min(Tn, t0 + DWR_SEG);
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) dw_load_in(x, b, t0 - padl + j, Tn, C, Cin, ch, inop, win[j]);
+            for (int tb = t0; tb < tend; tb += K) {
+                float nv[K][4], ng[K][4], dd[K][4];
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    const bool ok = tb + u < tend;
+                    dw_raw(x, b, ok ? tb + u - padl + K - 1 : -1, Tn, C, Cin, ch, inop, nv[u], ng[u]);
+                    if (ok) load4g(dy + ((size_t)b * Tn + tb + u) * C + ch, dd[u]);
+                    else { dd[u][0] = dd[u][1] = dd[u][2] = dd[u][3] = 0.f; }
+                }
+#pragma unroll
+                for (int u = 0; u < K; ++u) {
+                    const int t = tb + u;
+                    if (t < tend) {
+                        dw_xform(inop, nv[u], ng[u]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) win[(u + K - 1) % K][e] = nv[u][e];
+                        float d[4] = {dd[u][0], dd[u][1], dd[u][2], dd[u][3]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accb[e] += d[e];
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[j][e] += d[e] * win[(u + j) % K][e];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(red + j * C + ch + e, acc[j][e]);      // LDS atomics across the item lanes
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(red + K * C + ch + e, accb[e]);
+    }
+    __syncthreads();
+    float* dst = part + (size_t)blockIdx.x * (K + 1) * C;
+    for (int q = threadIdx.x; q < (K + 1) * C; q += 256) dst[q] = red[q];
+}
+
+// weight gradient, LDS tile + per-thread tap accumulators: thread = 4 channels x all K taps x 4 consecutive time steps
+// of a 32-step tile; the in(x) window slides through registers, so an item costs 2 LDS reads per K*4 FMAs (the older
+// tap-lane mapping below needs 5 reads per 16 FMAs and is LDS-bound).  Accumulators live across the items of the
+// workgroup; lanes are combined with LDS atomics and one partial row per workgroup goes to `part`.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_win_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part,
+                                                               int B, int Tn, int C, int padl, int inop) {
+    __shared__ __attribute__((aligned(16))) float xt[(DWG_TT + K - 1) * DW_CT];
+    __shared__ __attribute__((aligned(16))) float dt_[DWG_TT * DW_CT];
+    __shared__ float red[(K + 1) * DW_CT];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * DW_CT;
+    const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
+    constexpr int rows = DWG_TT + K - 1;
+    const int ntt = (Tn + DWG_TT - 1) / DWG_TT;
+    const int cl = tid & 31, tl = tid >> 5;          // 32 channel lanes x 8 time lanes (4 steps each)
+    for (int q = tid; q < (K + 1) * DW_CT; q += 256) red[q] = 0.f;
+    float acc[K][4], accb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
+    const int ch8 = c0 + (tid & 15) * 8;
+    for (int item = blockIdx.y; item < B * ntt; item += gridDim.y) {
+        const int b = item / ntt, t0 = (item % ntt) * DWG_TT;
+        __syncthreads();
+        for (int r = tid >> 4; r < rows; r += 16) {
+            const int tin = t0 - padl + r;
+            float v[8];
+            if (tin >= 0 && tin < Tn && ch8 < C) {
+                const T* p = x + ((size_t)b * Tn + tin) * Cin + ch8;
+                load8(p, v);
+                if (inop == DWIN_SWISH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+                } else if (inop == DWIN_GLU) {
+                    float g[8];
+                    load8(p + C, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(g[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            float* dst = xt + r * DW_CT + (tid & 15) * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        for (int r = tid >> 4; r < DWG_TT; r += 16) {
+            const int t = t0 + r;
+            float v[8];
+            if (t < Tn && ch8 < C) load8(dy + ((size_t)b * Tn + t) * C + ch8, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            float* dst = dt_ + r * DW_CT + (tid & 15) * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        __syncthreads();
+        float4 win[K];                                   // in(x) rows tl*4 + (0..K-1)
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) win[j + 1] = *reinterpret_cast<const float4*>(xt + (tl * 4 + j) * DW_CT + cl * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) win[j] = win[j + 1];
+            win[K - 1] = *reinterpret_cast<const float4*>(xt + (tl * 4 + u + K - 1) * DW_CT + cl * 4);
+            const float4 d = *reinterpret_cast<const float4*>(dt_ + (tl * 4 + u) * DW_CT + cl * 4);
+            accb[0] += d.x; accb[1] += d.y; accb[2] += d.z; accb[3] += d.w;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                acc[j][0] += d.x * win[j].x; acc[j][1] += d.y * win[j].y; acc[j][2] += d.z * win[j].z; acc[j][3] += d.w * win[j].w;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(red + j * DW_CT + cl * 4 + e, acc[j][e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(red + K * DW_CT + cl * 4 + e, accb[e]);
+    __syncthreads();
+    // part[(blockIdx.y)][K+1][C]
+    float* dst = part + (size_t)blockIdx.y * (K + 1) * C;
+    for (int q = tid; q < (K + 1) * DW_CT; q += 256) {
+        const int j = q / DW_CT, c = c0 + (q % DW_CT);
+        if (c < C) dst[(size_t)j * C + c] = red[q];
+    }
+}
+
+static bool dw_reg_ok(int C, int k) { return (k == 3 || k == 5) && C % 4 == 0   /* K = 11, 15 need > 250 VGPRs: LDS-tiled kernels */ && C / 4 <= 256 && 256 % (C / 4) == 0; }
+int g_force_dw_lds = 0;    // tests: force the LDS-tiled kernels
+
+template <typename T>
+static void launch_dw_reg(int k, const T* x, const float* w, const float* bias, T* y, const T* aux, float* ssum, float* ssq,
+                          int B, int Tn, int C, int padl, int inop, int outop, int flip, hipStream_t s) {
+    const int nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
+    dim3 grid((nseg * (C / 4) + 255) / 256, B);
+#define DWR(KK) hipLaunchKernelGGL((dwconv_reg_kernel<T, KK>), grid, dim3(256), 0, s, x, w, bias, y, aux, ssum, ssq, Tn, C, padl, inop, outop, flip)
+    switch (k) { case 3: DWR(3); break; case 5: DWR(5); break; case 11: DWR(11); break; default: DWR(15); break; }
+#undef DWR
+}
+#define DWG_BLOCKS 512
+template <typename T>
+static void launch_dw_wgrad_reg(int k, const T* dy, const T* x, float* part, int B, int Tn, int C, int padl, int inop, hipStream_t s) {
+    const size_t sh = (size_t)(k + 1) * C * sizeof(float);
+#define DWG(KK) hipLaunchKernelGGL((dwconv_wgrad_reg_kernel<T, KK>), dim3(DWG_BLOCKS), dim3(256), sh, s, dy, x, part, B, Tn, C, padl, inop)
+    switch (k) { case 3: DWG(3); break; case 5: DWG(5); break; case 11: DWG(11); break; default: DWG(15); break; }
+#undef DWG
+}
+size_t dwconv_bwd_scratch_floats(int C, int k) { return (size_t)DWG_BLOCKS * (k + 1) * C; }
+
 static int dwconv_check(int C, int k) {
     if (C % 8 != 0) { ishara_set_error("dwconv: C=%d must be a multiple of 8", C); return -1; }
     if (k < 1 || k > DW_MAXK) { ishara_set_error("dwconv: kernel size %d unsupported (1..%d)", k, DW_MAXK); return -1; }
@@ -324,6 +613,11 @@ static int dwconv_check(int C, int k) {
 int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const float* bias, void* y,
                       float* colsum, float* colsq, int B, int T, int C, int k, int padl, hipStream_t s) {
     if (dwconv_check(C, k)) return -1;
+    if (dw_reg_ok(C, k) && !g_force_dw_lds) {
+        if (dt == DT_BF16) launch_dw_reg<bf16>(k, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s);
+        else launch_dw_reg<float>(k, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s);
+        return LAUNCH_OK();
+    }
     dim3 grid((T + DW_TT - 1) / DW_TT, (C + DW_CT - 1) / DW_CT, B);
     if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0);
     else hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0);
@@ -450,16 +744,36 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 }
 
 int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const float* w, void* dx,
-                      float* dw, float* dbias, int B, int T, int C, int k, int padl, hipStream_t s) {
+                      float* dw, float* dbias, float* scratch, int B, int T, int C, int k, int padl, hipStream_t s) {
     if (dwconv_check(C, k)) return -1;
+    const int outop = inop == DWIN_SWISH ? OUT_DSWISH : (inop == DWIN_GLU ? OUT_DGLU : OUT_NONE);
+    const bool reg = dw_reg_ok(C, k) && !g_force_dw_lds;
     // data grad: correlation with flipped taps, left pad k-1-padl; then through the input op
-    {
+    if (reg) {
+        if (dt == DT_BF16) launch_dw_reg<bf16>(k, (const bf16*)dy, w, nullptr, (bf16*)dx, (const bf16*)x, nullptr, nullptr, B, T, C, k - 1 - padl, DWIN_NONE, outop, 1, s);
+        else launch_dw_reg<float>(k, (const float*)dy, w, nullptr, (float*)dx, (const float*)x, nullptr, nullptr, B, T, C, k - 1 - padl, DWIN_NONE, outop, 1, s);
+    } else {
         dim3 grid((T + DW_TT - 1) / DW_TT, (C + DW_CT - 1) / DW_CT, B);
-        const int outop = inop == DWIN_SWISH ? OUT_DSWISH : (inop == DWIN_GLU ? OUT_DGLU : OUT_NONE);
         if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, w, (const float*)nullptr, (bf16*)dx, (const bf16*)x, (float*)nullptr, (float*)nullptr, B, T, C, k, k - 1 - padl, (int)DWIN_NONE, outop, 1);
         else hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, w, (const float*)nullptr, (float*)dx, (const float*)x, (float*)nullptr, (float*)nullptr, B, T, C, k, k - 1 - padl, (int)DWIN_NONE, outop, 1);
     }
-    {
+    const bool winok = scratch && (k == 3 || k == 5 || k == 11 || k == 15) && !g_force_dw_lds;
+    if (winok) {
+        const int cblocks = (C + DW_CT - 1) / DW_CT;
+        const int ntt = (T + DWG_TT - 1) / DWG_TT;
+        const int splits = max(1, min(B * ntt, DWG_BLOCKS / cblocks));
+        dim3 grid(cblocks, splits);
+#define DWW(TT, KK) hipLaunchKernelGGL((dwconv_wgrad_win_kernel<TT, KK>), grid, dim3(256), 0, s, (const TT*)dy, (const TT*)x, scratch, B, T, C, padl, inop)
+#define DWWK(TT) switch (k) { case 3: DWW(TT, 3); break; case 5: DWW(TT, 5); break; case 11: DWW(TT, 11); break; default: DWW(TT, 15); break; }
+        if (dt == DT_BF16) { DWWK(bf16) } else { DWWK(float) }
+        launch_reduce_slabs(scratch, dw, k * C, splits, (size_t)(k + 1) * C, s);
+        if (dbias) launch_reduce_slabs(scratch + (size_t)k * C, dbias, C, splits, (size_t)(k + 1) * C, s);
+    } else if (reg && scratch) {   // weight / bias grad through per-workgroup partial rows
+        if (dt == DT_BF16) launch_dw_wgrad_reg<bf16>(k, (const bf16*)dy, (const bf16*)x, scratch, B, T, C, padl, inop, s);
+        else launch_dw_wgrad_reg<float>(k, (const float*)dy, (const float*)x, scratch, B, T, C, padl, inop, s);
+        launch_reduce_slabs(scratch, dw, k * C, DWG_BLOCKS, (size_t)(k + 1) * C, s);
+        if (dbias) launch_reduce_slabs(scratch + (size_t)k * C, dbias, C, DWG_BLOCKS, (size_t)(k + 1) * C, s);
+    } else {
         const int ntt = (T + DWG_TT - 1) / DWG_TT;
         const int cblocks = (C + DW_CT - 1) / DW_CT;
         int splits = max(1, min(B * ntt, 1024 / cblocks));

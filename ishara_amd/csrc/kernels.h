@@ -73,9 +73,11 @@ enum : int { DWIN_NONE = 0, DWIN_SWISH = 1, DWIN_GLU = 2 };
 // stats: ssum/ssq [B,C] = per-sample sum_t y, sum_t y^2 (fp32 atomics; zero them first; nullptr = off).
 int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const float* bias, void* y,
                       float* ssum, float* ssq, int B, int T, int C, int k, int padl, hipStream_t s);
-// dx = d in(x) ; dw [k,C], dbias [C] accumulated atomically.
+// dx = d in(x) ; dw [k,C], dbias [C] accumulated (through `scratch` partial rows of
+// dwconv_bwd_scratch_floats(C,k) floats when given, else atomically).
+size_t dwconv_bwd_scratch_floats(int C, int k);
 int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const float* w, void* dx,
-                      float* dw, float* dbias, int B, int T, int C, int k, int padl, hipStream_t s);
+                      float* dw, float* dbias, float* scratch, int B, int T, int C, int k, int padl, hipStream_t s);
 
 // BN finalize from per-sample sums ssum/ssq [nb,C] (count = rows they cover): mean, rstd,
 // a = gamma*rstd, b = beta - mean*a ; moving statistics update when training

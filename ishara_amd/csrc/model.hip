@@ -368,6 +368,7 @@ static void plan_workspace(ishara_model* m) {
     size_t slabf = 0;
     for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > slabf) slabf = f; }
     if (layernorm_bwd_scratch_floats(d) > slabf) slabf = layernorm_bwd_scratch_floats(d);
+    if (dwconv_bwd_scratch_floats(2 * maxw, 31) > slabf) slabf = dwconv_bwd_scratch_floats(2 * maxw, 31);
     m->slab = m->f32(slabf);
     m->ctcws = m->f32(ctc_workspace_floats(B, T, m->L));
     m->dlogits = m->f32(Mx * m->C);
@@ -609,7 +610,7 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
     CKP(m, "eca_bn_bwd_finalize", 0, 0, launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
                                   m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), B, T, c, m->s));
     CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.sg), m->Wf(m->E), 1, m->Wf(m->Fc), m->W(m->t1), B, T, c, m->s));
-    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, B, T, c, cb.k, cb.k - 1, m->s));
+    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s));
     EpiArgs e2; e2.resid = g;
     CK(gemm_dgrad(m, cb.W1, m->W(m->t2), dt, gn, r.M, OP_NONE, no, e2));
     CK(gemm_wgrad(m, cb.W1, x, dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
@@ -669,7 +670,7 @@ static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x,
     EpiArgs e1; e1.dact = DACT_SWISH; e1.aux = m->W(c.zd);
     CK(gemm_dgrad(m, c.Wc3, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e1));                                // dzd
     CK(gemm_wgrad(m, c.Wc3, m->W(c.hd), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, B, T, de, c.k, c.k - 1, m->s));   // dzc
+    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, m->Wf(m->slab), B, T, de, c.k, c.k - 1, m->s));   // dzc
     CK(gemm_dgrad(m, c.Wc1, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // dxn
     CK(gemm_wgrad(m, c.Wc1, m->W(c.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
     CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(c.mean), m->Wf(c.rstd), m->P(c.ln.gamma), g, gn, m->G(c.ln.gamma), m->G(c.ln.beta), m->Wf(m->slab), r.M, d, m->s));
@@ -685,7 +686,7 @@ static int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* 
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
     CKP(m, "bn_bwd_finalize", 0, 0, launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(c.bn.gamma), m->G(c.bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
     CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv
-    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
+    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
     EpiArgs e2; e2.resid = m->W(m->t1);
     CK(gemm_dgrad(m, c.Wp1, m->W(m->t3), dt, gn, r.M, OP_NONE, no, e2));
     CK(gemm_wgrad(m, c.Wp1, x, dt, OP_NONE, no, m->W(m->t3), dt, OP_NONE, no, r.M));
@@ -821,10 +822,10 @@ extern "C" int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, i
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern int g_force_regstage, g_dbg_tn, g_force_tn_regstage;
+extern int g_force_regstage, g_dbg_tn, g_force_tn_regstage, g_force_dw_lds;
 static int g_dbg_epi = 0;
-// bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bits 4-7: NT ablation; bits 8-11: TN ablation
-extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = on & 1; g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 15; g_force_tn_regstage = (on >> 1) & 1; return 0; }
+// bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bit 2: 1 LDS-tiled dwconv; bits 4-7: NT ablation; bits 8-11: TN ablation
+extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = on & 1; g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 15; g_force_tn_regstage = (on >> 1) & 1; g_force_dw_lds = (on >> 2) & 1; return 0; }
 
 // ---- operator tests: dense
 static void op_shadow_layout(int dt, int K, int N, size_t& wt, int& ldt, size_t& wn, int& ldn, size_t& slab, size_t& total, int M) {
@@ -873,9 +874,10 @@ extern "C" int ishara_op_dwconv_fwd(int32_t dt, int32_t inop, const void* x, con
                                     int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {
     return launch_dwconv_fwd(dt, inop, x, w, bias, y, ssum, ssq, B, T, C, k, padl, (hipStream_t)s);
 }
+extern "C" int64_t ishara_op_dwconv_scratch_bytes(int32_t C, int32_t k) { return (int64_t)(dwconv_bwd_scratch_floats(C, k) * sizeof(float)); }
 extern "C" int ishara_op_dwconv_bwd(int32_t dt, int32_t inop, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,
-                                    int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {
-    return launch_dwconv_bwd(dt, inop, dy, x, w, dx, dw, dbias, B, T, C, k, padl, (hipStream_t)s);
+                                    void* scratch, int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {
+    return launch_dwconv_bwd(dt, inop, dy, x, w, dx, dw, dbias, (float*)scratch, B, T, C, k, padl, (hipStream_t)s);
 }
 // scratch layout: q | k | vt | lse | delta
 extern "C" int64_t ishara_op_attn_scratch_bytes(int32_t B, int32_t H, int32_t T, int32_t dh) {

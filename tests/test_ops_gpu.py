@@ -114,9 +114,19 @@ def _dw_ref(x, w, bias, inop, padl, C_):
     return F.conv1d(up, w.t().unsqueeze(1), bias, groups=C_).transpose(1, 2)
 
 
+@pytest.mark.parametrize("variant", ["reg", "lds"])   # register-window kernels (K in 3,5,11,15) vs LDS-tiled kernels
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("B,T,Cc,k,inop,causal", [(3, 176, 128, 11, 1, True), (2, 64, 256, 3, 1, True), (2, 384, 64, 15, 2, False), (2, 40, 8, 5, 0, True), (1, 16, 512, 31, 2, False)])
-def test_dwconv(lib, dt, B, T, Cc, k, inop, causal):
+@pytest.mark.parametrize("B,T,Cc,k,inop,causal", [(3, 176, 128, 11, 1, True), (2, 64, 256, 3, 1, True), (2, 384, 64, 15, 2, False), (2, 40, 8, 5, 0, True),
+                                                 (1, 16, 512, 31, 2, False), (2, 48, 512, 5, 1, True), (2, 104, 32, 15, 2, False)])
+def test_dwconv(lib, dt, B, T, Cc, k, inop, causal, variant):
+    lib.ishara_debug_force_regstage(4 if variant == "lds" else 0)
+    try:
+        _dwconv(lib, dt, B, T, Cc, k, inop, causal, variant)
+    finally:
+        lib.ishara_debug_force_regstage(0)
+
+
+def _dwconv(lib, dt, B, T, Cc, k, inop, causal, variant):
     code, tdt = DT[dt]
     g = torch.Generator().manual_seed(T + k)
     Cin = 2 * Cc if inop == 2 else Cc
@@ -141,7 +151,8 @@ def test_dwconv(lib, dt, B, T, Cc, k, inop, causal):
     dx = torch.empty(B, T, Cin, dtype=tdt, device="cuda")
     dw = torch.zeros(k, Cc, device="cuda")
     dbias = torch.zeros(Cc, device="cuda") if bias is not None else None
-    _lib.check(lib.ishara_op_dwconv_bwd(code, inop, _lib.ptr(dyd), _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dbias), B, T, Cc, k, padl, stream()))
+    scr = torch.empty(int(lib.ishara_op_dwconv_scratch_bytes(Cc, k)), dtype=torch.uint8, device="cuda") if variant == "reg" else None
+    _lib.check(lib.ishara_op_dwconv_bwd(code, inop, _lib.ptr(dyd), _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dbias), _lib.ptr(scr), B, T, Cc, k, padl, stream()))
     close(dx, xr.grad, "dw_dx", **TOL[dt])
     close(dw, wr.grad, "dw_dw", rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * (B * T) ** 0.5)
     if bias is not None:
