@@ -117,6 +117,9 @@ int ishara_debug_force_regstage(int32_t on);
 int64_t ishara_op_scratch_bytes(int32_t M, int32_t K, int32_t N);
 int ishara_op_dense_fwd(int32_t dt, const void* x, const float* W, const float* bias, void* y,
                         int32_t M, int32_t K, int32_t N, int32_t act, void* scratch, ishara_stream s);
+/* y = act(x @ W + b) + resid   (resid may be NULL) */
+int ishara_op_dense_fwd_ex(int32_t dt, const void* x, const float* W, const float* bias, const void* resid, void* y,
+                           int32_t M, int32_t K, int32_t N, int32_t act, void* scratch, ishara_stream s);
 /* dx = dy @ W^T ; dW += x^T dy ; db += colsum(dy) */
 int ishara_op_dense_bwd(int32_t dt, const void* x, const float* W, const void* dy, void* dx,
                         float* dW, float* db, int32_t M, int32_t K, int32_t N, void* scratch, ishara_stream s);

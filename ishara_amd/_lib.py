@@ -57,6 +57,7 @@ SIGNATURES = {
     "ishara_debug_force_regstage": (C.c_int, [_I32]),
     "ishara_op_scratch_bytes": (_I64, [_I32, _I32, _I32]),
     "ishara_op_dense_fwd": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "ishara_op_dense_fwd_ex": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "ishara_op_dense_bwd": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "ishara_op_layernorm_fwd": (C.c_int, [_I32, _P, _P, _P, _F, _P, _P, _P, _I32, _I32, _P]),
     "ishara_op_layernorm_bwd": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P]),

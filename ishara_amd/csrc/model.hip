@@ -852,6 +852,18 @@ extern "C" int ishara_op_dense_fwd(int32_t dt, const void* x, const float* Wm, c
     OpArgs no; EpiArgs ea; ea.bias = bias; ea.act = act; ea.dbg = g_dbg_epi;
     return launch_gemm_nt(dt, dt, dt, OP_NONE, x, sc + wt, y, M, N, K, ldt, no, ea, s);
 }
+// y = act(x @ W + b) + resid
+extern "C" int ishara_op_dense_fwd_ex(int32_t dt, const void* x, const float* Wm, const float* bias, const void* resid, void* y,
+                                      int32_t M, int32_t K, int32_t N, int32_t act, void* scratch, ishara_stream st) {
+    hipStream_t s = (hipStream_t)st;
+    size_t wt, wn, slab, total; int ldt, ldn;
+    op_shadow_layout(dt, K, N, wt, ldt, wn, ldn, slab, total, M);
+    char* sc = (char*)scratch;
+    HIP_CHECK_RET(hipMemsetAsync(sc, 0, slab, s));
+    CK(launch_make_shadow(dt, Wm, K, N, sc + wt, ldt, sc + wn, ldn, s));
+    OpArgs no; EpiArgs ea; ea.bias = bias; ea.act = act; ea.resid = resid;
+    return launch_gemm_nt(dt, dt, dt, OP_NONE, x, sc + wt, y, M, N, K, ldt, no, ea, s);
+}
 extern "C" int ishara_op_dense_bwd(int32_t dt, const void* x, const float* Wm, const void* dy, void* dx, float* dW, float* db,
                                    int32_t M, int32_t K, int32_t N, void* scratch, ishara_stream st) {
     hipStream_t s = (hipStream_t)st;
