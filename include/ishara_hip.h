@@ -99,6 +99,11 @@ int ishara_profile_report(ishara_model* m, char* buf, int32_t cap);
 /* decode_phrase (c8:4-12) for a batch: out_idx [B,T] int32 (-1 padded), out_len [B]. */
 int ishara_greedy_decode(const float* logits, int32_t B, int32_t T, int32_t C, int32_t blank,
                          int32_t* out_idx, int32_t* out_len, ishara_stream s);
+/* pre_process1(*pre_process00(x)) of the TFLite wrapper (c3:61-115, c13:9-15): raw [max_frames,276] landmarks with NaNs
+ * (SEL_COLS order, c1:22-26), clip length read from device memory (*n_frames), mean/std [276] in output order
+ * -> out [T,276].  One kernel, graph-capturable. */
+int ishara_preprocess(const float* raw, const int32_t* n_frames, int32_t max_frames, const float* mean, const float* stdv,
+                      float* out, int32_t T, ishara_stream s);
 /* tf.nn.ctc_loss alone: nll [B]; dlogits [B,T,C] may be NULL; ws = ishara_ctc_workspace_bytes. */
 int64_t ishara_ctc_workspace_bytes(int32_t B, int32_t T, int32_t L);
 int ishara_ctc_loss(const float* logits, const int64_t* labels, int32_t B, int32_t T, int32_t C,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "ishara_profile_enable": (C.c_int, [_P, _I32]),
     "ishara_profile_report": (C.c_int, [_P, C.c_char_p, _I32]),
     "ishara_greedy_decode": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "ishara_preprocess": (C.c_int, [_P, _P, _I32, _P, _P, _P, _I32, _P]),
     "ishara_ctc_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ishara_ctc_loss": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _F, _P, _P]),
     "ishara_dropout_mask": (C.c_int, [_U32, _U32, _I32, _I32, _F, _P, _P]),

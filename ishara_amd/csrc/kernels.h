@@ -135,6 +135,9 @@ int launch_ctc(const float* logits, const int64_t* labels, int B, int T, int C, 
 int launch_mean(const float* v, float* out, int n, float scale, hipStream_t s);
 int launch_greedy_decode(const float* logits, int B, int T, int C, int blank, int* out_idx, int* out_len, hipStream_t s);
 
+// ---- inference preprocessing (preprocess.hip): raw [max_frames,276] (+ device clip length) -> [T,276]; mean/std [276] in OUTPUT order
+int launch_preprocess(const float* raw, const int* n_frames, int max_frames, const float* mean, const float* stdv, float* out, int T, hipStream_t s);
+
 // ---- optimizer (optimizer.hip) -----------------------------------------------------------
 struct RAdamArgs { float lr, wd, beta1, beta2, eps, c1, c2, r_t; int rect; int sync; float slow_step; };
 int launch_radam_lookahead(float* theta, const float* grad, float* m, float* v, float* slow, int64_t n,

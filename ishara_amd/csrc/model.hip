@@ -827,6 +827,12 @@ static int g_dbg_epi = 0;
 // bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bit 2: 1 LDS-tiled dwconv; bits 4-7: NT ablation; bits 8-11: TN ablation
 extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = on & 1; g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 15; g_force_tn_regstage = (on >> 1) & 1; g_force_dw_lds = (on >> 2) & 1; return 0; }
 
+extern "C" int ishara_preprocess(const float* raw, const int32_t* n_frames, int32_t max_frames, const float* mean, const float* stdv,
+                                 float* out, int32_t T, ishara_stream s) {
+    if (max_frames <= 0 || max_frames > 8192) { ishara_set_error("ishara_preprocess: max_frames %d unsupported (1..8192)", max_frames); return -1; }
+    return launch_preprocess(raw, n_frames, max_frames, mean, stdv, out, T, (hipStream_t)s);
+}
+
 // ---- operator tests: dense
 static void op_shadow_layout(int dt, int K, int N, size_t& wt, int& ldt, size_t& wn, int& ldn, size_t& slab, size_t& total, int M) {
     const int bk = dt == DT_BF16 ? 64 : 32;

@@ -1,0 +1,65 @@
+// Inference-side preprocessing of the reference's TFLite wrapper (conv-hybrid-model.ipynb c3:61-115, c13:9-15) as ONE
+// single-workgroup kernel: frame filter (hand present or even frame), NaN-pad / bilinear resize over time to T frames,
+// per-landmark normalisation, [T,92,3] -> [T,276] re-ordering, NaN -> 0.  The clip length is read from device memory so
+// the launch can live inside a captured hipGraph.
+#include "kernels.h"
+
+#define PP_LM 92
+#define PP_COLS 276
+
+// part table (concat order c3:111: lip, rhand, lhand, rpose, lpose): first landmark in the output, offset inside an
+// axis block of SEL_COLS (c1:22-26: right hand, left hand, LPOSE, RPOSE, lips)
+__device__ __constant__ int pp_out0[5] = {0, 40, 61, 82, 87};
+__device__ __constant__ int pp_src0[5] = {52, 0, 21, 47, 42};
+
+__global__ __launch_bounds__(1024) void preprocess_kernel(const float* __restrict__ raw, const int* __restrict__ n_frames_p, int max_frames,
+                                                          const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                          float* __restrict__ out, int Tn) {
+    extern __shared__ int sh[];            // keep[max_frames] -> compacted source index list
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    int n = *n_frames_p;
+    n = n < 0 ? 0 : (n > max_frames ? max_frames : n);
+    // ---- frame mask: any hand landmark present (NaN -> 0, sum != 0) or even frame (c3:89-93)
+    for (int f = tid; f < n; f += blockDim.x) {
+        float s = 0.f;
+        for (int a = 0; a < 3; ++a)
+            for (int j = 0; j < 42; ++j) { const float v = raw[(size_t)f * PP_COLS + a * PP_LM + j]; s += (v != v) ? 0.f : v; }
+        sh[f] = (s != 0.f || (f & 1) == 0) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {                        // n <= a few hundred: serial compaction
+        int m = 0;
+        for (int f = 0; f < n; ++f) if (sh[f]) sh[m++] = f;
+        s_n = m;
+    }
+    __syncthreads();
+    const int m = s_n;
+    const float ratio = m > 0 ? (float)m / (float)Tn : 1.f;
+    for (int i = tid; i < Tn * PP_COLS; i += blockDim.x) {
+        const int t = i / PP_COLS, c = i - t * PP_COLS;
+        const int lm = c / 3, axis = c - lm * 3;
+        int part = 0;
+#pragma unroll
+        for (int p = 1; p < 5; ++p) if (lm >= pp_out0[p]) part = p;
+        const int col = axis * PP_LM + pp_src0[part] + (lm - pp_out0[part]);
+        float v;
+        if (n == 0) v = t == 0 ? 0.f : __builtin_nanf("");     // empty clip -> ONE all-zero frame, NaN padded (c13:11, c3:3-4)
+        else if (m < Tn) v = t < m ? raw[(size_t)sh[t] * PP_COLS + col] : __builtin_nanf("");       // NaN pad (c3:3-4)
+        else {                                                 // tf.image.resize bilinear, half-pixel centres (c3:6)
+            float src = ((float)t + 0.5f) * ratio - 0.5f;
+            src = src < 0.f ? 0.f : src;
+            int i0 = (int)floorf(src); i0 = i0 > m - 1 ? m - 1 : i0;
+            const int i1 = i0 + 1 > m - 1 ? m - 1 : i0 + 1;
+            const float w = src - (float)i0;
+            v = raw[(size_t)sh[i0] * PP_COLS + col] * (1.f - w) + raw[(size_t)sh[i1] * PP_COLS + col] * w;
+        }
+        v = (v - mean[c]) / stdv[c];
+        out[i] = (v != v) ? 0.f : v;                           // NaN -> 0 (c3:114)
+    }
+}
+
+int launch_preprocess(const float* raw, const int* n_frames, int max_frames, const float* mean, const float* stdv, float* out, int T, hipStream_t s) {
+    hipLaunchKernelGGL(preprocess_kernel, dim3(1), dim3(1024), (size_t)max_frames * sizeof(int), s, raw, n_frames, max_frames, mean, stdv, out, T);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
