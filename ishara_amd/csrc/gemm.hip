@@ -449,40 +449,51 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const TA* __restrict__ A, 
 #define GL_NSTAGE 4
 DEVI int gl_f(int row) { return ((row >> 3) & 1) << 1; }      // conflict-free slot swizzle for 64-byte rows (brute-forced)
 
+// per-lane state of the LDS-DMA NT kernel: everything the K loop needs is computed once; per K tile the loop only
+// bumps three global pointers by one tile and uses compile-time stage offsets (the loop is unrolled over the ring)
 template <typename TM>
-DEVI void glds_issue(const TM* __restrict__ A, const TM* __restrict__ Bt, int M, int K, int ldb, int m0, int n0, int kt,
-                     char* stage, int wid, int lane) {
-    constexpr int EPC = MmaCfg<TM>::EPC, BKH = MmaCfg<TM>::BK / 2;
-    const int r = lane >> 2, sp = lane & 3;                 // 16 rows x 4 slots per 1 KB piece
-    const int kcol = kt * BKH + ((sp ^ gl_f(r)) * EPC);     // logical slot that lands in physical slot sp of row r
-    {                                                       // A: 4 pieces of 16 rows, one per wave
-        const int row = min(m0 + 16 * wid + r, M - 1);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (size_t)row * K + kcol),
-                                         (__attribute__((address_space(3))) void*)(stage + wid * 1024), 16, 0, 0);
-    }
+struct GlState {
+    const TM* pa;            // this lane's 16-byte source of the A piece (row clamp + swizzle applied)
+    const TM* pb[2];         // ... of the two B pieces
+    int offA[2], offB[4];    // byte offsets of the MFMA fragment reads inside a stage (k-step 0)
+};
+
+template <typename TM>
+DEVI void gl_init(GlState<TM>& g, const TM* __restrict__ A, const TM* __restrict__ Bt, int M, int K, int ldb, int m0, int n0,
+                  int wid, int wr, int wc, int lane) {
+    constexpr int EPC = MmaCfg<TM>::EPC;
+    const int r = lane >> 2, sp = lane & 3;
+    const int kcol = (sp ^ gl_f(r)) * EPC;
+    g.pa = A + (size_t)min(m0 + 16 * wid + r, M - 1) * K + kcol;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {                           // B: 8 pieces, two per wave
-        const int j = wid + 4 * u;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bt + (size_t)(n0 + 16 * j + r) * ldb + kcol),
-                                         (__attribute__((address_space(3))) void*)(stage + 4096 + j * 1024), 16, 0, 0);
-    }
+    for (int u = 0; u < 2; ++u) g.pb[u] = Bt + (size_t)(n0 + 16 * (wid + 4 * u) + r) * ldb + kcol;
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int row = wr * 32 + 16 * i + fr; g.offA[i] = row * 64 + (is_bf16_t<TM>::value ? ((fg ^ gl_f(row)) << 4) : (gl_f(row) << 4) + fg * 4); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int row = wc * 64 + 16 * j + fr; g.offB[j] = 4096 + row * 64 + (is_bf16_t<TM>::value ? ((fg ^ gl_f(row)) << 4) : (gl_f(row) << 4) + fg * 4); }
 }
 
 template <typename TM>
-DEVI void mma_tile_2x4(const char* ldsA, const char* ldsB, int wr, int wc, int lane, f32x4 (&acc)[2][4]) {
-    const int r = lane & 15, g = lane >> 4;
+DEVI void gl_issue(GlState<TM>& g, char* stage, int wid) {
+    constexpr int BKH = MmaCfg<TM>::BK / 2;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g.pa,
+                                     (__attribute__((address_space(3))) void*)(stage + wid * 1024), 16, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g.pb[u],
+                                         (__attribute__((address_space(3))) void*)(stage + 4096 + (wid + 4 * u) * 1024), 16, 0, 0);
+    g.pa += BKH; g.pb[0] += BKH; g.pb[1] += BKH;
+}
+
+template <typename TM>
+DEVI void gl_mma(const GlState<TM>& g, const char* st, f32x4 (&acc)[2][4]) {
     if constexpr (is_bf16_t<TM>::value) {
         bf16x8 a[2], b[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wr * 32 + 16 * i + r;
-            a[i] = *reinterpret_cast<const bf16x8*>(ldsA + row * 64 + ((g ^ gl_f(row)) << 4));
-        }
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + g.offA[i]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = wc * 64 + 16 * j + r;
-            b[j] = *reinterpret_cast<const bf16x8*>(ldsB + row * 64 + ((g ^ gl_f(row)) << 4));
-        }
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + g.offB[j]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -490,18 +501,12 @@ DEVI void mma_tile_2x4(const char* ldsA, const char* ldsB, int wr, int wc, int l
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 4; ++s) {          // f32: 4 k-steps of 4 per 64-byte row; slot s -> physical slot s ^ f(row): XOR the precomputed f-slot
             float a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wr * 32 + 16 * i + r;
-                a[i] = *reinterpret_cast<const float*>(ldsA + row * 64 + ((s ^ gl_f(row)) << 4) + g * 4);
-            }
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float*>(st + (g.offA[i] ^ (s << 4)));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wc * 64 + 16 * j + r;
-                b[j] = *reinterpret_cast<const float*>(ldsB + row * 64 + ((s ^ gl_f(row)) << 4) + g * 4);
-            }
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float*>(st + (g.offB[j] ^ (s << 4)));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -540,20 +545,26 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_glds_kernel(const TM* __restri
     const int mw = m0 + wr * 32, nw = n0 + wc * 64;
     EpiRows<TC, 4> er;       // thread -> columns (lane&7)*8.., rows (lane>>3) + 8q
     er.prefetch(mw + (lane >> 3), 8, nw + (lane & 7) * 8, M, N, ea);
+    GlState<TM> gs;
+    gl_init<TM>(gs, A, Bt, M, K, ldb, m0, n0, wid, wr, wc, lane);
 #pragma unroll
     for (int st = 0; st < GL_NSTAGE - 1; ++st)
-        if (st < nk && ld_on) glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, st, smem + st * GL_STAGE, wid, lane);
-    for (int kt = 0; kt < nk; ++kt) {
-        // 3 DMA per wave per K tile; up to two later tiles stay in flight across the barrier
-        const int ahead = min(nk - 1 - kt, GL_NSTAGE - 2);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // tile kt landed for every wave; tile kt-1 fully consumed
-        if (kt + GL_NSTAGE - 1 < nk && ld_on)
-            glds_issue<TM>(A, Bt, M, K, ldb, m0, n0, kt + GL_NSTAGE - 1, smem + ((kt + GL_NSTAGE - 1) % GL_NSTAGE) * GL_STAGE, wid, lane);
-        const char* st = smem + (kt % GL_NSTAGE) * GL_STAGE;
-        if (mma_on) mma_tile_2x4<TM>(st, st + 4096, wr, wc, lane, acc);
+        if (st < nk && ld_on) gl_issue<TM>(gs, smem + st * GL_STAGE, wid);
+    for (int kt0 = 0; kt0 < nk; kt0 += GL_NSTAGE) {
+#pragma unroll
+        for (int u = 0; u < GL_NSTAGE; ++u) {      // stage index u is a compile-time constant: LDS offsets fold into the instructions
+            const int kt = kt0 + u;
+            if (kt < nk) {
+                // 3 DMA per wave per K tile; up to two later tiles stay in flight across the barrier
+                const int ahead = min(nk - 1 - kt, GL_NSTAGE - 2);
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; tile kt-1 fully consumed
+                if (kt + GL_NSTAGE - 1 < nk && ld_on) gl_issue<TM>(gs, smem + ((u + GL_NSTAGE - 1) % GL_NSTAGE) * GL_STAGE, wid);
+                if (mma_on) gl_mma<TM>(gs, smem + u * GL_STAGE, acc);
+            }
+        }
     }
     __syncthreads();     // ring is free: reuse it as four wave-private fp32 stages
     if (ea.dbg & 1) { if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][3][2]); return; }
@@ -601,6 +612,277 @@ static int run_nt_glds(const void* A, const void* Bt, void* C, int M, int N, int
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---------------------------------------------------------------------------------
+// NT kernel v2 ("T"): 128x128 tile, LDS-DMA ring of 3 x 16 KB (K tile 32 bf16 / 16 f32, 64-byte rows), 4 waves (2x2),
+// wave tile 64x64 held TRANSPOSED: acc[j][i] = mfma(Bt fragment, A fragment) so that a lane owns, for row
+// m = 16i + (lane&15), the 4 CONSECUTIVE output columns n = 16j + 4*(lane>>4) .. +3.  The epilogue therefore runs
+// straight from the accumulators — 8-byte (bf16) / 16-byte (f32) loads of residual / act' operands and stores of C per
+// lane, no LDS staging, no block barrier — and the weight tile is re-read from L2 half as often as with 64-row tiles.
+// ---------------------------------------------------------------------------------
+#define GT_STAGE 16384
+#define GT_NSTAGE 3
+
+template <typename TM>
+struct GtState {
+    const TM* pa[2];
+    const TM* pb[2];
+    int offA[4], offB[4];
+};
+
+template <typename T> DEVI void load4t(const T* p, float (&v)[4]) { load4g(p, v); }
+template <typename T> DEVI void store4t(T* p, const float (&v)[4]) { store4(p, v); }
+
+// EK: 0 generic run-time-flag epilogue; 1 fast "C = acc + bias"; 2 fast "C = acc + bias + resid" (the epilogue is
+// instruction-issue bound: the generic one costs ~800 instructions per wave-tile, the fast ones ~150)
+template <typename TM, typename TC, int EK>
+__global__ __launch_bounds__(256, 3) void gemm_nt_t_kernel(const TM* __restrict__ A, const TM* __restrict__ Bt, TC* __restrict__ C,
+                                                           int M, int N, int K, int ldb, EpiArgs ea) {
+    __shared__ __attribute__((aligned(16))) char smem[GT_NSTAGE * GT_STAGE];
+    constexpr int EPC = MmaCfg<TM>::EPC, BK = MmaCfg<TM>::BK / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int nMt = (M + 127) >> 7, nNt = (N + 127) >> 7;
+    const int ntiles = nMt * nNt;
+    const int nk = K / BK;
+    const int c = lane & 15, g = lane >> 4;
+    const int dmodel = ea.H * ea.dh;
+
+    // tile id -> (mt, nt); XCD-aware (blocks b, b+8 share an L2): the N tiles of one A row-panel stay on one XCD
+    auto tile_of = [&](int id, int& mt, int& nt) {
+        if ((nMt & 7) == 0) { const int xcd = id & 7, local = id >> 3; mt = (local / nNt) * 8 + xcd; nt = local % nNt; }
+        else { mt = id / nNt; nt = id % nNt; }
+    };
+    GtState<TM> gs;
+    auto setup = [&](int m0, int n0) {
+        const int r = lane >> 2, sp = lane & 3;
+        const int kcol = (sp ^ gl_f(r)) * EPC;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {     // 8 sixteen-row pieces per operand; wave takes pieces wid, wid+4
+            gs.pa[u] = A + (size_t)min(m0 + 16 * (wid + 4 * u) + r, M - 1) * K + kcol;
+            gs.pb[u] = Bt + (size_t)(n0 + 16 * (wid + 4 * u) + r) * ldb + kcol;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + 16 * i + c, rb = wc * 64 + 16 * i + c;
+        gs.offA[i] = ra * 64 + (is_bf16_t<TM>::value ? ((g ^ gl_f(ra)) << 4) : (gl_f(ra) << 4) + g * 4);
+        gs.offB[i] = 8192 + rb * 64 + (is_bf16_t<TM>::value ? ((g ^ gl_f(rb)) << 4) : (gl_f(rb) << 4) + g * 4);
+    }
+    auto issue = [&](char* stage) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gs.pa[u],
+                                             (__attribute__((address_space(3))) void*)(stage + (wid + 4 * u) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gs.pb[u],
+                                             (__attribute__((address_space(3))) void*)(stage + 8192 + (wid + 4 * u) * 1024), 16, 0, 0);
+            gs.pa[u] += BK; gs.pb[u] += BK;
+        }
+    };
+
+    // ---- persistent loop over this workgroup's tiles.  The first two DMA stages of tile t+1 are issued BEFORE the
+    // epilogue of tile t, so one workgroup's C stores overlap its own next loads (and workgroups drift out of phase).
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int mt, nt;
+    tile_of(tile, mt, nt);
+    setup(mt << 7, nt << 7);
+#pragma unroll
+    for (int st = 0; st < GT_NSTAGE - 1; ++st)
+        if (st < nk) issue(smem + st * GT_STAGE);
+    bool first = true;
+    while (true) {
+        const int m0 = mt << 7, n0 = nt << 7;
+        f32x4 acc[4][4];       // acc[j][i]: n tile j, m tile i
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nl = n0 + wc * 64 + 4 * g;          // + 16j
+        float bias[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[j][e] = (ea.bias && nl + 16 * j + e < N) ? ea.bias[nl + 16 * j + e] : 0.f;
+
+        for (int kt0 = 0; kt0 < nk; kt0 += GT_NSTAGE) {
+#pragma unroll
+            for (int u = 0; u < GT_NSTAGE; ++u) {
+                const int kt = kt0 + u;
+                if (kt < nk) {
+                    // 4 DMA per wave per K tile, one later tile in flight.  At the first K tile of a later output tile the
+                    // previous epilogue's loads/stores are younger than these DMAs in the in-order counter: drain everything.
+                    if (kt + 1 < nk && (kt > 0 || first)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (kt + GT_NSTAGE - 1 < nk) issue(smem + ((u + GT_NSTAGE - 1) % GT_NSTAGE) * GT_STAGE);
+                    const char* st = smem + u * GT_STAGE;
+                    if constexpr (is_bf16_t<TM>::value) {
+                        bf16x8 a[4], b[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { a[i] = *reinterpret_cast<const bf16x8*>(st + gs.offA[i]); b[i] = *reinterpret_cast<const bf16x8*>(st + gs.offB[i]); }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            float a[4], b[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { a[i] = *reinterpret_cast<const float*>(st + (gs.offA[i] ^ (s << 4))); b[i] = *reinterpret_cast<const float*>(st + (gs.offB[i] ^ (s << 4))); }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[j][i], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- next tile: once every wave has finished reading the ring, start its first DMA stages, then run the epilogue
+        const int ntile = tile + gridDim.x;
+        const bool more = ntile < ntiles;
+        int mt2 = 0, nt2 = 0;
+        if (more) {
+            tile_of(ntile, mt2, nt2);
+            __builtin_amdgcn_s_barrier();
+            setup(mt2 << 7, nt2 << 7);
+#pragma unroll
+            for (int st = 0; st < GT_NSTAGE - 1; ++st)
+                if (st < nk) issue(smem + st * GT_STAGE);
+        }
+        if constexpr (EK != 0) {
+            // ---- fast epilogue: one base pointer per lane, rows 16 apart, column groups 16 apart
+            const int mrow = m0 + wr * 64 + c;
+            TC* cb = C + (size_t)mrow * N + nl;
+            const TC* rb = reinterpret_cast<const TC*>(ea.resid) + (size_t)mrow * N + nl;
+            const bool full = (m0 + 128 <= M) && (n0 + 128 <= N);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!full && mrow + 16 * i >= M) continue;
+                float ext[4][4];
+                if constexpr (EK == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (full || nl + 16 * j < N) load4t(rb + (size_t)(16 * i) * N + 16 * j, ext[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!full && nl + 16 * j >= N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bias[j][e];
+                    if constexpr (EK == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += ext[j][e];
+                    }
+                    store4t(cb + (size_t)(16 * i) * N + 16 * j, v);
+                }
+            }
+        } else if (!(ea.dbg & 1)) {
+            // ---- epilogue straight from the accumulators: row m = .. + 16i + c, columns nl + 16j .. +3
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wr * 64 + 16 * i + c;
+                if (m >= M) continue;
+                const size_t rowoff = (size_t)m * N;
+                float ext[4][4];
+                const bool need_res = ea.resid != nullptr, need_aux = ea.dact != DACT_NONE;
+                if (need_res || need_aux) {           // batch the residual (or act') loads of the 4 column groups
+                    const TC* src = reinterpret_cast<const TC*>(need_res ? ea.resid : ea.aux);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (nl + 16 * j < N) load4t(src + rowoff + nl + 16 * j, ext[j]);
+                    }
+                }
+                const float rsc = ea.rowscale ? ea.rowscale[m / ea.T] : 1.f;
+                const uint32_t rk = ea.drop.thr ? rng_row_key(ea.drop.key, (uint32_t)m) : 0u;
+                const int bsamp = (ea.mode == EPI_QKV) ? m / ea.T : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nl + 16 * j;
+                    if (n >= N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bias[j][e];
+                    if (ea.addtab) {
+                        float t4[4];
+                        load4(ea.addtab + (size_t)(m % ea.tab_period) * N + n, t4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += t4[e];
+                    }
+                    if (ea.pre_out) store4t(reinterpret_cast<TC*>(ea.pre_out) + rowoff + n, v);
+                    if (ea.act == ACT_SWISH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = swishf_(v[e]);
+                    } else if (ea.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (ea.drop.thr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rng_keep(rk, (uint32_t)(n + e), ea.drop.thr) ? v[e] * ea.drop.scale : 0.f;
+                    }
+                    if (ea.rowscale) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= rsc;
+                    }
+                    if (need_aux) {
+                        float a4[4];
+                        if (need_res) load4t(reinterpret_cast<const TC*>(ea.aux) + rowoff + n, a4);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a4[e] = ext[j][e];
+                        }
+                        if (ea.dact == DACT_SWISH) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= dswishf_(a4[e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = a4[e] > 0.f ? v[e] : 0.f;
+                        }
+                    }
+                    if (need_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += ext[j][e];
+                    }
+                    if (ea.mode == EPI_STD) {
+                        store4t(C + rowoff + n, v);
+                    } else {      // q,k [B,H,T,dh] rows (8-byte stores); v transposed to vt [B,H,dh,T] (2-byte stores, 1/3 of one GEMM in 30)
+                        int h, part, ii;
+                        if (ea.head_major) { h = n / (3 * ea.dh); const int w = n - h * 3 * ea.dh; part = w / ea.dh; ii = w - part * ea.dh; }
+                        else { part = n / dmodel; const int w = n - part * dmodel; h = w / ea.dh; ii = w - h * ea.dh; }
+                        const int t = m - bsamp * ea.T;
+                        if (part < 2) {
+                            store4t(reinterpret_cast<TC*>(part == 0 ? ea.q : ea.k) + ((size_t)(bsamp * ea.H + h) * ea.T + t) * ea.dh + ii, v);
+                        } else {
+                            TC* dst = reinterpret_cast<TC*>(ea.vt) + ((size_t)(bsamp * ea.H + h) * ea.dh + ii) * ea.T + t;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dst[(size_t)e * ea.T] = from_f<TC>(v[e]);
+                        }
+                    }
+                }
+            }
+        } else if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][3][2]);
+        if (!more) break;
+        tile = ntile; mt = mt2; nt = nt2; first = false;
+    }
+}
+
+template <typename TM, typename TC>
+static int run_nt_t(const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s) {
+    const int nMt = (M + 127) / 128, nNt = (N + 127) / 128;
+    const int ntiles = nMt * nNt;
+    const int grid = ntiles < 768 ? ntiles : 768;         // persistent: 3 workgroups per CU, each walks tiles `grid` apart
+    const bool fast = ea.addtab == nullptr && ea.pre_out == nullptr && ea.act == ACT_NONE && ea.drop.thr == 0 && ea.rowscale == nullptr &&
+                      ea.dact == DACT_NONE && ea.mode == EPI_STD && ea.dbg == 0;
+    if (fast && ea.resid) hipLaunchKernelGGL((gemm_nt_t_kernel<TM, TC, 2>), dim3(grid), dim3(256), 0, s, (const TM*)A, (const TM*)Bt, (TC*)C, M, N, K, ldb, ea);
+    else if (fast) hipLaunchKernelGGL((gemm_nt_t_kernel<TM, TC, 1>), dim3(grid), dim3(256), 0, s, (const TM*)A, (const TM*)Bt, (TC*)C, M, N, K, ldb, ea);
+    else hipLaunchKernelGGL((gemm_nt_t_kernel<TM, TC, 0>), dim3(grid), dim3(256), 0, s, (const TM*)A, (const TM*)Bt, (TC*)C, M, N, K, ldb, ea);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <typename TA, typename TM, typename TC, int OP>
 static int run_nt(const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s) {
     const int nMt = (M + 127) / 128, nNt = (N + 127) / 128;
@@ -624,7 +906,7 @@ static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int 
 // name of the kernel launch_gemm_nt / launch_gemm_tn will pick (profiler keys = rocprof kernel names)
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int K, int ldb);
 const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb);
-int g_force_regstage = 0;   // 0: LDS-DMA 64x128 kernel whenever eligible (default); 1: always the register-staged 128x128 kernel
+int g_force_regstage = 0;   // NT kernel choice: 0 LDS-DMA 128x128 transposed-accumulator kernel (default), 2 LDS-DMA 64x128 kernel, 1 register-staged
 int g_dbg_tn = 0;           // ablation bits for the TN kernel: 1 skip MFMA, 2 skip LDS stores, 4 skip global loads
 
 int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
@@ -637,7 +919,13 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
         ishara_set_error("gemm_nt: QKV split needs T, dh multiples of 8 (T=%d dh=%d)", ea.T, ea.dh); return -1;
     }
     const int bk = dtM == DT_BF16 ? 32 : 16;     // K tile of the LDS-DMA kernel
-    if (op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0 && !g_force_regstage) {
+    const bool dma_ok = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0;
+    if (dma_ok && g_force_regstage == 0 && N % 4 == 0 && (ea.mode != EPI_QKV || ea.dh % 4 == 0)) {
+        if (dtM == DT_F32 && dtC == DT_F32) return run_nt_t<float, float>(A, Bt, C, M, N, K, ldb, ea, s);
+        if (dtM == DT_BF16 && dtC == DT_BF16) return run_nt_t<bf16, bf16>(A, Bt, C, M, N, K, ldb, ea, s);
+        if (dtM == DT_BF16 && dtC == DT_F32) return run_nt_t<bf16, float>(A, Bt, C, M, N, K, ldb, ea, s);
+    }
+    if (dma_ok && g_force_regstage != 1) {
         if (dtM == DT_F32 && dtC == DT_F32) return run_nt_glds<float, float>(A, Bt, C, M, N, K, ldb, ea, s);
         if (dtM == DT_BF16 && dtC == DT_BF16) return run_nt_glds<bf16, bf16>(A, Bt, C, M, N, K, ldb, ea, s);
         if (dtM == DT_BF16 && dtC == DT_F32) return run_nt_glds<bf16, float>(A, Bt, C, M, N, K, ldb, ea, s);
@@ -882,7 +1170,8 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(const bf16* __restrict_
 #pragma unroll
     for (int st = 0; st < TR_NSTAGE - 1; ++st)
         if (st < nmc && !(dbg & 4)) tr_issue(A, B, Ka, Nb, k0, n0, m_beg + st * TR_ROWS, smem + st * TR_STAGE, wid, lane);
-    for (int mc = 0; mc < nmc; ++mc) {
+    const int nmc_run = (dbg & 16) ? 0 : nmc;
+    for (int mc = 0; mc < nmc_run; ++mc) {
         // 4 DMA per wave per tile; tiles mc+1, mc+2 may stay in flight
         const int ahead = min(nmc - 1 - mc, TR_NSTAGE - 2);
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -1106,8 +1395,9 @@ int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt,
 
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int K, int ldb) {
     const int bk = dtM == DT_BF16 ? 32 : 16;
-    const bool glds = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0 && !g_force_regstage;
-    if (glds) return dtM == DT_F32 ? "gemm_nt_glds_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_glds_kernel<bf16,f32>" : "gemm_nt_glds_kernel<bf16,bf16>");
+    const bool dma = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0;
+    if (dma && g_force_regstage == 0) return dtM == DT_F32 ? "gemm_nt_t_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_t_kernel<bf16,f32>" : "gemm_nt_t_kernel<bf16,bf16>");
+    if (dma && g_force_regstage != 1) return dtM == DT_F32 ? "gemm_nt_glds_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_glds_kernel<bf16,f32>" : "gemm_nt_glds_kernel<bf16,bf16>");
     if (dtA == DT_F32 && dtM == DT_BF16) return "gemm_nt_kernel<f32,bf16,bf16>";
     if (dtM == DT_F32) return "gemm_nt_kernel<f32,f32,f32>";
     return dtC == DT_F32 ? "gemm_nt_kernel<bf16,bf16,f32>" : "gemm_nt_kernel<bf16,bf16,bf16>";

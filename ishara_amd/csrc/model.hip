@@ -824,8 +824,8 @@ extern "C" int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, i
 
 extern int g_force_regstage, g_dbg_tn, g_force_tn_regstage, g_force_dw_lds;
 static int g_dbg_epi = 0;
-// bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bit 2: 1 LDS-tiled dwconv; bits 4-7: NT ablation; bits 8-11: TN ablation
-extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = on & 1; g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 15; g_force_tn_regstage = (on >> 1) & 1; g_force_dw_lds = (on >> 2) & 1; return 0; }
+// bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bit 2: 1 LDS-tiled dwconv; bit 3: 1 LDS-DMA 64x128 NT kernel; bits 4-7: NT ablation; bits 8-11: TN ablation
+extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = (on & 1) ? 1 : ((on >> 3) & 1 ? 2 : 0); g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 31; g_force_tn_regstage = (on >> 1) & 1; g_force_dw_lds = (on >> 2) & 1; return 0; }
 
 extern "C" int ishara_preprocess(const float* raw, const int32_t* n_frames, int32_t max_frames, const float* mean, const float* stdv,
                                  float* out, int32_t T, ishara_stream s) {

@@ -34,7 +34,7 @@ def close(got, ref, name, rtol, atol):
     assert worst <= 0, f"{name}: max abs err {float(err.max()):.3e} (ref scale {float(ref.abs().max()):.3e}), exceeds tol by {worst:.3e}"
 
 
-@pytest.mark.parametrize("regstage", [0, 1, 3])   # bit0: register-staged NT (else LDS-DMA); bit1: register-transposing TN (else tr-read)
+@pytest.mark.parametrize("regstage", [0, 8, 1, 3])   # NT: 0 LDS-DMA 128x128 transposed-acc, 8 LDS-DMA 64x128, bit0 register-staged; bit1: register-transposing TN
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0), (3000, 768, 256, 0), (1024, 512, 256, 0), (4096, 128, 128, 0)])
 def test_dense_fwd_bwd(lib, dt, M, K, N, act, regstage):

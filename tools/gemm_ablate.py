@@ -19,8 +19,7 @@ for (M, K, N) in shapes:
     sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
     scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
     res = {}
-    variants = {"glds": 0, "glds-noepi": 1 << 4, "glds-nomma": 2 << 4, "glds-noload": 4 << 4, "glds-onlyepi": 6 << 4,
-                "glds-onlyload": 3 << 4, "regstage": 1}
+    variants = {"glds": 0, "glds-noepi": 1 << 4, "glds64": 8, "regstage": 1}
     for rnd in range(3):
         for name, flag in variants.items():
             lib.ishara_debug_force_regstage(flag)
