@@ -904,9 +904,12 @@ static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int 
 }
 
 // name of the kernel launch_gemm_nt / launch_gemm_tn will pick (profiler keys = rocprof kernel names)
-const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int K, int ldb);
+const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
+const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea);
 const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb);
-int g_force_regstage = 0;   // NT kernel choice: 0 LDS-DMA 128x128 transposed-accumulator kernel (default), 2 LDS-DMA 64x128 kernel, 1 register-staged
+int g_force_regstage = 0;   // NT kernel choice: 0 A-stationary kernel (gemm_as.hip) where it applies, else the 128x128 LDS-DMA tile kernel; 3 tile kernel only; 2 LDS-DMA 64x128 kernel; 1 register-staged
+bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
+int launch_gemm_nt_as(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s);
 int g_dbg_tn = 0;           // ablation bits for the TN kernel: 1 skip MFMA, 2 skip LDS stores, 4 skip global loads
 
 int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
@@ -920,7 +923,11 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
     }
     const int bk = dtM == DT_BF16 ? 32 : 16;     // K tile of the LDS-DMA kernel
     const bool dma_ok = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0;
-    if (dma_ok && g_force_regstage == 0 && N % 4 == 0 && (ea.mode != EPI_QKV || ea.dh % 4 == 0)) {
+    if (dma_ok && g_force_regstage == 0 && dtM == DT_BF16) {
+        const int rc = launch_gemm_nt_as(dtC, A, Bt, C, M, N, K, ldb, ea, s);
+        if (rc != 1) return rc;
+    }
+    if (dma_ok && (g_force_regstage == 0 || g_force_regstage == 3) && N % 4 == 0 && (ea.mode != EPI_QKV || ea.dh % 4 == 0)) {
         if (dtM == DT_F32 && dtC == DT_F32) return run_nt_t<float, float>(A, Bt, C, M, N, K, ldb, ea, s);
         if (dtM == DT_BF16 && dtC == DT_BF16) return run_nt_t<bf16, bf16>(A, Bt, C, M, N, K, ldb, ea, s);
         if (dtM == DT_BF16 && dtC == DT_F32) return run_nt_t<bf16, float>(A, Bt, C, M, N, K, ldb, ea, s);
@@ -1393,10 +1400,11 @@ int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt,
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int K, int ldb) {
+const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea) {
     const int bk = dtM == DT_BF16 ? 32 : 16;
     const bool dma = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0;
-    if (dma && g_force_regstage == 0) return dtM == DT_F32 ? "gemm_nt_t_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_t_kernel<bf16,f32>" : "gemm_nt_t_kernel<bf16,bf16>");
+    if (dma && g_force_regstage == 0 && dtM == DT_BF16 && gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return gemm_nt_as_name(dtC, K, ea);
+    if (dma && (g_force_regstage == 0 || g_force_regstage == 3)) return dtM == DT_F32 ? "gemm_nt_t_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_t_kernel<bf16,f32>" : "gemm_nt_t_kernel<bf16,bf16>");
     if (dma && g_force_regstage != 1) return dtM == DT_F32 ? "gemm_nt_glds_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_glds_kernel<bf16,f32>" : "gemm_nt_glds_kernel<bf16,bf16>");
     if (dtA == DT_F32 && dtM == DT_BF16) return "gemm_nt_kernel<f32,bf16,bf16>";
     if (dtM == DT_F32) return "gemm_nt_kernel<f32,f32,f32>";

@@ -1,0 +1,409 @@
+// gemm_as.hip — "A-stationary" NT GEMM for the tall-skinny products of the encoder (gfx950).
+//
+//   C[M,N] = epi( A[M,K] . Bt[N,K]^T ),  bf16 operands, fp32 accumulate, K in {256, 512}, N <= 1024, M ~ 1e5.
+//
+// Every dense / pointwise-conv product of the model (reference notebook cells c6-c8: Dense / Conv1D(kernel 1) layers)
+// has a tiny weight matrix (<= 512 KB, L2 resident) and a huge activation matrix that must be streamed from HBM exactly
+// once.  A tile kernel re-stages BOTH operands through LDS for every output tile (~400 MB of L2->LDS DMA per launch at
+// M=98304, K=256, N=512, and one barrier per 32-wide K step).  Here instead
+//   * each wave keeps its 32 rows x full K of A as MFMA fragments in registers, loaded once straight from global
+//     memory with the whole K in flight (no LDS, no barrier on the activation side);
+//   * only the weight matrix streams through LDS: a ring of 3 x 16 KB stages filled by LDS-DMA, one stage = NS weight
+//     rows (output columns) x full K, shared by the workgroup's 4 waves; one barrier per NS output columns;
+//   * accumulators are held transposed (acc = mfma(Bt fragment, A fragment)), so a lane owns 4 consecutive output
+//     columns of one row per 16-column MFMA tile; for bf16 C the weight rows fed to a PAIR of tiles are permuted
+//     (tile jj of the pair takes staged rows 8*(t>>2) + 4*jj + (t&3), t = 0..15) so that the lane's 4 + 4 values are 8
+//     CONSECUTIVE columns: the epilogue runs straight from registers with 16-byte loads / stores, 64 contiguous bytes
+//     per row per instruction.  (tools/micro/store_depth.hip: the unpermuted 8-byte stores reach 4.0 TB/s of HBM write,
+//     the 16-byte ones 5.9 TB/s.)  The permutation is free: it only changes the LDS address of the fragment read.
+// The VM counter retires loads, stores and LDS-DMA in issue order, so the waits on the DMA ring are counted
+// (`s_waitcnt vmcnt(N)`); partial row blocks fall back to vmcnt(0).  The residual loads of the fast epilogue are ordinary
+// loads issued right after the barrier and BEFORE the step's DMA, consumed after the MFMA phase.  (Issuing them one
+// step ahead by inline asm does not survive register allocation: hipcc copies the destination registers at the loop
+// back-edge while the loads are still in flight.)
+#include <cstdio>
+#include <map>
+#include <string>
+#include <type_traits>
+#include "common.h"
+#include "kernels.h"
+
+#define AS_NS 32            // output columns (staged weight rows) per step
+#define AS_MAXN 1024
+
+typedef __attribute__((ext_vector_type(4))) uint32_t as_u32x4;
+
+template <int N> DEVI void as_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// swizzle of a staged weight row: 16-byte chunk q of row r sits at position q ^ as_swz(r).  Uses row bits 0,1,3 so that
+// both fragment-row patterns (r = 16j + c and the paired r = 8*(c>>2) + 4*jj + (c&3)) give 8 distinct values over any
+// 8 consecutive lanes (conflict-free ds_read_b128).
+DEVI int as_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <int GW, typename T> DEVI void as_st(T* p, const float (&v)[GW]) {
+    if constexpr (GW == 8) store8(p, v); else store4(p, v);
+}
+// 16 bytes of TC -> GW floats (8 bf16 / 4 f32)
+template <typename TC, int GW> DEVI void as_unpack(const as_u32x4& r, float (&v)[GW]) {
+    if constexpr (GW == 8) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { v[2 * h] = __uint_as_float(r[h] << 16); v[2 * h + 1] = __uint_as_float(r[h] & 0xffff0000u); }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) v[h] = __uint_as_float(r[h]);
+    }
+}
+
+// epilogue features, compiled in per kernel instantiation (AS_ALL: every feature behind its run-time flag)
+enum { AS_RESID = 1, AS_DACT = 2, AS_ACT = 4, AS_DROP = 8, AS_ROWSCALE = 16, AS_PREOUT = 32, AS_QKV = 64, AS_ADDTAB = 128, AS_ALL = 255 };
+template <int MASK, int F> DEVI bool as_on(bool runtime) {
+    if constexpr ((MASK & F) == 0) return false;
+    else if constexpr (MASK == AS_ALL) return runtime;
+    else return true;
+}
+
+// One pass of a workgroup over all N columns for the rows [m_base, m_base + 64*RT): wave w owns rows m_base + 16*RT*w ..,
+// RT row tiles of 16.  KT = K / 32 (8 or 16); MASK: epilogue features.
+template <typename TC, int KT, int MASK, int RT>
+DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, const EpiArgs& ea,
+                  char* smem, const float* bias_s, int m_base) {
+    constexpr int RB = KT * 64;                    // bytes of one staged weight row (full K)
+    constexpr int NS = AS_NS;                      // output columns per step
+    constexpr int STAGE = NS * RB;                 // 16 KB (K=256) / 32 KB (K=512)
+    constexpr int R = KT <= 8 ? 3 : 2;             // ring depth: 48 KB / 64 KB of LDS
+    constexpr int K = KT * 32;
+    constexpr int DPW = STAGE / 1024 / 4;          // 1 KB DMA instructions per wave per stage
+    constexpr bool PAIR = is_bf16_t<TC>::value;    // pair MFMA tiles so that a lane owns 8 consecutive columns (16-byte bf16 accesses)
+    constexpr int GW = PAIR ? 8 : 4;               // columns per lane per group
+    constexpr int NG = NS / (4 * GW);              // groups per row tile per step: 1 (bf16 C) / 2 (f32 C)
+    constexpr int SPS = RT * NG;                   // stores per lane per step
+    constexpr bool COUNTED = (MASK & (AS_RESID | AS_DACT | AS_ADDTAB | AS_QKV)) == 0;   // epilogue = a fixed number of stores, no loads
+    constexpr int OPS = SPS * ((MASK & AS_PREOUT) ? 2 : 1);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int mw = m_base + wid * 16 * RT;                   // first row of this wave
+    const bool full = m_base + 64 * RT <= M;
+    const int nsteps = N / NS;
+    const int dmodel = ea.H * ea.dh;
+    const bool f_resid = as_on<MASK, AS_RESID>(ea.resid != nullptr), f_dact = as_on<MASK, AS_DACT>(ea.dact != DACT_NONE);
+    const bool f_act = as_on<MASK, AS_ACT>(ea.act != ACT_NONE), f_drop = as_on<MASK, AS_DROP>(ea.drop.thr != 0);
+    const bool f_rowscale = as_on<MASK, AS_ROWSCALE>(ea.rowscale != nullptr), f_preout = as_on<MASK, AS_PREOUT>(ea.pre_out != nullptr);
+    const bool f_qkv = as_on<MASK, AS_QKV>(ea.mode == EPI_QKV), f_addtab = as_on<MASK, AS_ADDTAB>(ea.addtab != nullptr);
+
+    // weight DMA: instruction u = wid*DPW + t moves bytes [u*1024, +1024) of the stage; 16-byte chunk p of row r holds
+    // source chunk p ^ as_swz(r) (swizzle on the source address: the LDS image of an LDS-DMA is lane-linear)
+    const bf16* bsrc[DPW];
+#pragma unroll
+    for (int t = 0; t < DPW; ++t) {
+        const int o = (wid * DPW + t) * 1024 + lane * 16;
+        const int r = o / RB, p = (o % RB) >> 4;
+        bsrc[t] = Bt + (size_t)r * ldb + ((p ^ as_swz(r)) << 3);
+    }
+    const size_t bstep = (size_t)NS * ldb;
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int t = 0; t < DPW; ++t) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc[t],
+                                             (__attribute__((address_space(3))) void*)(smem + slot + (wid * DPW + t) * 1024), 16, 0, 0);
+            bsrc[t] += bstep;
+        }
+    };
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st)
+        if (st < nsteps && !(ea.dbg & 8)) issue(st * STAGE);       // dbg: ablation bits of tools/gemm_ablate.py (1 no epilogue, 2 no MFMA, 4 no LDS reads, 8 no DMA)
+
+    // A fragments: lane (c, g) holds row 16i + c, k = 32kt + 8g .. +7
+    bf16x8 a[RT][KT];
+    int mrow[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        mrow[i] = min(mw + 16 * i + c, M - 1);
+        const bf16x8* p = reinterpret_cast<const bf16x8*>(A + (size_t)mrow[i] * K + g * 8);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) a[i][kt] = p[kt * 4];
+    }
+
+    // weight fragment reads: MFMA tile j, tile row t = c comes from staged row
+    //   PAIR: 8*(c>>2) + (c&3) + 4*(j&1)   (j = 0,1)        else: 16*j + c
+    // chunk 4kt + g of that row sits at position (4kt + g) ^ swz; swz does not depend on j.
+    const int frow = PAIR ? 8 * (c >> 2) + (c & 3) : c;
+    const int sx = g ^ as_swz(frow);
+    const int off_e = frow * RB + ((sx & 3) << 4) + ((sx >> 2) << 6);
+    const int off_o = frow * RB + ((sx & 3) << 4) + (((sx >> 2) ^ 1) << 6);
+    constexpr int JSTRIDE = (PAIR ? 4 : 16) * RB;
+
+    // per-row constants
+    float rsc[RT];
+    uint32_t rk[RT];
+    int bsamp[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int m = mw + 16 * i + c;
+        rsc[i] = 1.f; rk[i] = 0u; bsamp[i] = 0;
+        if (f_rowscale || f_qkv) bsamp[i] = mrow[i] / ea.T;
+        if (f_rowscale) rsc[i] = ea.rowscale[bsamp[i]];
+        if (f_drop) rk[i] = rng_row_key(ea.drop.key, (uint32_t)m);
+    }
+
+    // per-lane base offsets of the [M, N] operands (rows clamped: out-of-range rows load row M-1 and store nothing)
+    size_t eoff[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) eoff[i] = (size_t)mrow[i] * N + GW * g;
+    const TC* resid = reinterpret_cast<const TC*>(ea.resid);
+    const TC* aux = reinterpret_cast<const TC*>(ea.aux);
+
+    int slot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // ---- T1: stage s has landed.  Younger operations that may stay in flight (in-order VM counter): the DMAs of
+        // stages s+1 .. s+R-2 and, when the epilogue is a fixed number of stores and the row block is full, the stores
+        // of the R-1 steps since its issue.
+        if constexpr (COUNTED) {
+            if (full && s >= R - 1 && s + R - 2 < nsteps) as_wait_vm<(R - 2) * DPW + (R - 1) * OPS>(); else as_wait_vm<0>();
+        } else {
+            if (s + R - 2 < nsteps) as_wait_vm<(R - 2) * DPW>(); else as_wait_vm<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int n0 = s * NS;
+        // ---- T3: residual / act' operand loads of this step (consumed after the MFMA phase), then DMA of stage s+R-1
+        // into the slot read in step s-1
+        as_u32x4 rs[RT][NG], au[RT][NG];
+        if (f_resid) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int q = 0; q < NG; ++q) rs[i][q] = *reinterpret_cast<const as_u32x4*>(resid + eoff[i] + n0 + 4 * GW * q);
+        }
+        if (f_dact) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int q = 0; q < NG; ++q) au[i][q] = *reinterpret_cast<const as_u32x4*>(aux + eoff[i] + n0 + 4 * GW * q);
+        }
+        if (s + R - 1 < nsteps && !(ea.dbg & 8)) issue(slot == 0 ? (R - 1) * STAGE : slot - STAGE);
+        // ---- MFMA: acc[j][i] = sum_k Bt[row(j), k] * A[16i + .., k]
+        f32x4 acc[2][RT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* st = smem + slot;
+        if (!(ea.dbg & 6)) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(st + ((kt & 1) ? off_o : off_e) + (kt >> 1) * 128 + j * JSTRIDE);
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i][kt], acc[j][i], 0, 0, 0);
+                }
+            }
+        } else if (!(ea.dbg & 4)) {       // LDS reads only
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(st + ((kt & 1) ? off_o : off_e) + (kt >> 1) * 128 + j * JSTRIDE);
+                    acc[j][0] += b;
+                }
+        } else if (!(ea.dbg & 2)) {       // MFMA only
+            const bf16x8 b = a[0][0];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i][kt], acc[j][i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[0][i][0] = (float)a[i][0][0] + (float)a[i][KT - 1][7];
+        }
+        if (ea.dbg & 1) { if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][RT - 1][2]); slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE; continue; }
+        // ---- epilogue from the accumulators: lane owns row 16i + c and, per group q, columns n0 + 4*GW*q + GW*g .. +GW-1
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const int n = n0 + 4 * GW * q + GW * g;
+            float bias[GW];
+#pragma unroll
+            for (int h = 0; h < GW / 4; ++h) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + n + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias[4 * h + e] = bv[e];
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int m = mw + 16 * i + c;
+                if (!full && m >= M) continue;
+                const size_t off = eoff[i] + n0 + 4 * GW * q;          // = m*N + n
+                float v[GW];
+                if constexpr (PAIR) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[0][i][e] + bias[e]; v[4 + e] = acc[1][i][e] + bias[4 + e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[q][i][e] + bias[e];
+                }
+                if (f_addtab) {
+                    const float* tp = ea.addtab + (size_t)(m % ea.tab_period) * N + n;
+#pragma unroll
+                    for (int h = 0; h < GW / 4; ++h) {
+                        float t4[4];
+                        load4(tp + 4 * h, t4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * h + e] += t4[e];
+                    }
+                }
+                if (f_preout) as_st<GW>(reinterpret_cast<TC*>(ea.pre_out) + off, v);
+                if (f_act) {
+                    if (ea.act == ACT_SWISH) {
+#pragma unroll
+                        for (int e = 0; e < GW; ++e) v[e] = swishf_(v[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < GW; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                }
+                if (f_drop) {
+#pragma unroll
+                    for (int e = 0; e < GW; ++e) v[e] = rng_keep(rk[i], (uint32_t)(n + e), ea.drop.thr) ? v[e] * ea.drop.scale : 0.f;
+                }
+                if (f_rowscale) {
+#pragma unroll
+                    for (int e = 0; e < GW; ++e) v[e] *= rsc[i];
+                }
+                if (f_dact) {
+                    float x[GW];
+                    as_unpack<TC, GW>(au[i][q], x);
+                    if (ea.dact == DACT_SWISH) {
+#pragma unroll
+                        for (int e = 0; e < GW; ++e) v[e] *= dswishf_(x[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < GW; ++e) v[e] = x[e] > 0.f ? v[e] : 0.f;
+                    }
+                }
+                if (f_resid) {
+                    float x[GW];
+                    as_unpack<TC, GW>(rs[i][q], x);
+#pragma unroll
+                    for (int e = 0; e < GW; ++e) v[e] += x[e];
+                }
+                if (!f_qkv) {
+                    as_st<GW>(C + off, v);
+                } else {      // q,k [B,H,T,dh] rows; v transposed to vt [B,H,dh,T]   (GW consecutive columns stay inside one head: dh % 8 == 0)
+                    int h, part, ii;
+                    if (ea.head_major) { h = n / (3 * ea.dh); const int w = n - h * 3 * ea.dh; part = w / ea.dh; ii = w - part * ea.dh; }
+                    else { part = n / dmodel; const int w = n - part * dmodel; h = w / ea.dh; ii = w - h * ea.dh; }
+                    const int t = m - bsamp[i] * ea.T;
+                    if (part < 2) {
+                        as_st<GW>(reinterpret_cast<TC*>(part == 0 ? ea.q : ea.k) + ((size_t)(bsamp[i] * ea.H + h) * ea.T + t) * ea.dh + ii, v);
+                    } else {
+                        TC* dst = reinterpret_cast<TC*>(ea.vt) + ((size_t)(bsamp[i] * ea.H + h) * ea.dh + ii) * ea.T + t;
+#pragma unroll
+                        for (int e = 0; e < GW; ++e) dst[(size_t)e * ea.T] = from_f<TC>(v[e]);
+                    }
+                }
+            }
+        }
+        slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE;
+    }
+}
+
+// K = 256: 128-row workgroups, 3 per CU (768 at M = 98304 = one round of the chip).  K = 512: the A fragments take 128
+// VGPRs, so only 2 workgroups fit per CU; 192-row workgroups (512 at M = 98304, again exactly one round) run as a
+// 128-row pass followed by a 64-row pass.
+template <typename TC, int KT, int MASK>
+__global__ __launch_bounds__(256, KT <= 8 ? 3 : 2) void gemm_nt_as_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C,
+                                                                         int M, int N, int ldb, EpiArgs ea) {
+    constexpr int R = KT <= 8 ? 3 : 2;
+    constexpr int STAGE = AS_NS * KT * 64;
+    __shared__ __attribute__((aligned(16))) char smem[R * STAGE + AS_MAXN * 4];
+    float* bias_s = reinterpret_cast<float*>(smem + R * STAGE);
+    // bias -> LDS (visible after the first barrier of the step loop)
+    for (int n = threadIdx.x; n < N; n += 256) bias_s[n] = ea.bias ? ea.bias[n] : 0.f;
+    if constexpr (KT <= 8) {
+        as_pass<TC, KT, MASK, 2>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
+    } else {
+        const int m_base = blockIdx.x * 192;
+        as_pass<TC, KT, MASK, 2>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base);
+        if (m_base + 128 < M) {
+            __builtin_amdgcn_s_barrier();          // every wave is done reading the ring before the second pass refills it
+            as_pass<TC, KT, MASK, 1>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base + 128);
+        }
+    }
+}
+
+static int as_mask_of(const EpiArgs& ea) {
+    return (ea.resid ? AS_RESID : 0) | (ea.dact != DACT_NONE ? AS_DACT : 0) | (ea.act != ACT_NONE ? AS_ACT : 0) | (ea.drop.thr ? AS_DROP : 0) |
+           (ea.rowscale ? AS_ROWSCALE : 0) | (ea.pre_out ? AS_PREOUT : 0) | (ea.mode == EPI_QKV ? AS_QKV : 0) | (ea.addtab ? AS_ADDTAB : 0);
+}
+
+// the instantiation run_as picks for a feature mask (bf16 C: the listed combinations, else AS_ALL; f32 C: 0 or AS_ALL)
+static int as_inst_mask(bool c_bf16, int mask) {
+    if (!c_bf16) return mask == 0 ? 0 : AS_ALL;
+    switch (mask) {
+        case 0: case AS_RESID: case AS_RESID | AS_ROWSCALE: case AS_RESID | AS_DROP: case AS_ACT | AS_PREOUT: case AS_ACT | AS_PREOUT | AS_DROP:
+        case AS_ACT | AS_DROP: case AS_ACT: case AS_DACT: case AS_DACT | AS_DROP: case AS_QKV: return mask;
+        default: return AS_ALL;
+    }
+}
+
+#define AS_LAUNCH(MASK) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK>), grid, block, 0, s, (const bf16*)A, (const bf16*)Bt, (TC*)C, M, N, ldb, ea)
+template <typename TC, int KT>
+static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea, hipStream_t s) {
+    constexpr int BR = KT <= 8 ? 128 : 192;      // rows per workgroup
+    const dim3 grid((M + BR - 1) / BR), block(256);
+    const int mask = as_mask_of(ea);
+    if constexpr (is_bf16_t<TC>::value) {
+        // the feature combinations the encoder's forward / backward passes use (model.hip), compiled without the others
+        switch (mask) {
+            case 0: AS_LAUNCH(0); break;
+            case AS_RESID: AS_LAUNCH(AS_RESID); break;                                           // W2 / Wb / Wp eval, dgrad + skip gradient
+            case AS_RESID | AS_ROWSCALE: AS_LAUNCH(AS_RESID | AS_ROWSCALE); break;               // conv block W2 with drop-path
+            case AS_RESID | AS_DROP: AS_LAUNCH(AS_RESID | AS_DROP); break;                       // Wb / Wp with output dropout
+            case AS_ACT | AS_PREOUT: AS_LAUNCH(AS_ACT | AS_PREOUT); break;                       // FFN Wa eval
+            case AS_ACT | AS_PREOUT | AS_DROP: AS_LAUNCH(AS_ACT | AS_PREOUT | AS_DROP); break;   // FFN Wa training
+            case AS_ACT | AS_DROP: AS_LAUNCH(AS_ACT | AS_DROP); break;                           // head
+            case AS_ACT: AS_LAUNCH(AS_ACT); break;
+            case AS_DACT: AS_LAUNCH(AS_DACT); break;                                             // dgrad through swish / relu
+            case AS_DACT | AS_DROP: AS_LAUNCH(AS_DACT | AS_DROP); break;
+            case AS_QKV: AS_LAUNCH(AS_QKV); break;
+            default: AS_LAUNCH(AS_ALL); break;
+        }
+    } else {
+        if (mask == 0) AS_LAUNCH(0); else AS_LAUNCH(AS_ALL);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+#undef AS_LAUNCH
+
+bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
+    (void)dtC;
+    if (K != 256 && K != 512) return false;
+    if (N % AS_NS != 0 || N > AS_MAXN || ldb < K || ldb % 8 != 0 || M < 1) return false;
+    if (ea.mode == EPI_QKV && (ea.dh % 8 != 0 || ea.T % 8 != 0)) return false;
+    return true;
+}
+
+// profiler key = the rocprof kernel name of the instantiation launch_gemm_nt_as runs
+const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea) {
+    static std::map<int, std::string> names;
+    const int inst = as_inst_mask(dtC == DT_BF16, as_mask_of(ea));
+    const int id = (dtC == DT_BF16 ? 0 : 1 << 20) | (K << 8) | inst;
+    auto it = names.find(id);
+    if (it == names.end()) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, inst);
+        it = names.emplace(id, buf).first;
+    }
+    return it->second.c_str();
+}
+
+// returns 1 when the shape is not one this kernel takes (caller falls through to the tile kernels)
+int launch_gemm_nt_as(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s) {
+    if (!gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return 1;
+    if (dtC == DT_BF16) return K == 256 ? run_as<bf16, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<bf16, 16>(A, Bt, C, M, N, ldb, ea, s);
+    return K == 256 ? run_as<float, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<float, 16>(A, Bt, C, M, N, ldb, ea, s);
+}

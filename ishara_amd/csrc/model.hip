@@ -456,12 +456,12 @@ extern "C" int ishara_sync_weights(ishara_model* m, ishara_stream st) {
 static int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea) {
     if (w.b >= 0) ea.bias = m->P(w.b);
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtC) * (1 + (ea.resid ? 1 : 0) + (ea.pre_out ? 1 : 0)) + (double)w.K * w.N * dt_size(m->dt);
-    CKP(m, gemm_nt_kernel_name(dtA, m->dt, dtC, aop, A, w.K, w.ldt), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, dtC, aop, A, m->ws + w.wt, Cc, M, w.N, w.K, w.ldt, oa, ea, m->s));
+    CKP(m, gemm_nt_kernel_name(dtA, m->dt, dtC, aop, A, M, w.N, w.K, w.ldt, ea), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, dtC, aop, A, m->ws + w.wt, Cc, M, w.N, w.K, w.ldt, oa, ea, m->s));
     return 0;
 }
 static int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea) {
     const double by = (double)M * w.N * dt_size(dtA) + (double)M * w.K * dt_size(m->dt) * (1 + (ea.resid ? 1 : 0) + (ea.aux ? 1 : 0)) + (double)w.K * w.N * dt_size(m->dt);
-    CKP(m, gemm_nt_kernel_name(dtA, m->dt, m->dt, aop, dY, w.N, w.ldn), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
+    CKP(m, gemm_nt_kernel_name(dtA, m->dt, m->dt, aop, dY, M, w.K, w.N, w.ldn, ea), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
     return 0;
 }
 static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M) {
@@ -824,8 +824,8 @@ extern "C" int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, i
 
 extern int g_force_regstage, g_dbg_tn, g_force_tn_regstage, g_force_dw_lds;
 static int g_dbg_epi = 0;
-// bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bit 2: 1 LDS-tiled dwconv; bit 3: 1 LDS-DMA 64x128 NT kernel; bits 4-7: NT ablation; bits 8-11: TN ablation
-extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = (on & 1) ? 1 : ((on >> 3) & 1 ? 2 : 0); g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 31; g_force_tn_regstage = (on >> 1) & 1; g_force_dw_lds = (on >> 2) & 1; return 0; }
+// bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bit 2: 1 LDS-tiled dwconv; bit 3: 1 LDS-DMA 64x128 NT kernel; bits 4-7: NT ablation; bits 8-12: TN ablation; bit 13: 1 tile NT kernel instead of the A-stationary one
+extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = (on & 1) ? 1 : ((on >> 3) & 1 ? 2 : ((on >> 13) & 1 ? 3 : 0)); g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 31; g_force_tn_regstage = (on >> 1) & 1; g_force_dw_lds = (on >> 2) & 1; return 0; }
 
 extern "C" int ishara_preprocess(const float* raw, const int32_t* n_frames, int32_t max_frames, const float* mean, const float* stdv,
                                  float* out, int32_t T, ishara_stream s) {
@@ -867,7 +867,7 @@ extern "C" int ishara_op_dense_fwd_ex(int32_t dt, const void* x, const float* Wm
     char* sc = (char*)scratch;
     HIP_CHECK_RET(hipMemsetAsync(sc, 0, slab, s));
     CK(launch_make_shadow(dt, Wm, K, N, sc + wt, ldt, sc + wn, ldn, s));
-    OpArgs no; EpiArgs ea; ea.bias = bias; ea.act = act; ea.resid = resid;
+    OpArgs no; EpiArgs ea; ea.bias = bias; ea.act = act; ea.resid = resid; ea.dbg = g_dbg_epi;
     return launch_gemm_nt(dt, dt, dt, OP_NONE, x, sc + wt, y, M, N, K, ldt, no, ea, s);
 }
 extern "C" int ishara_op_dense_bwd(int32_t dt, const void* x, const float* Wm, const void* dy, void* dx, float* dW, float* db,

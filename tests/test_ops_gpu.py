@@ -34,9 +34,12 @@ def close(got, ref, name, rtol, atol):
     assert worst <= 0, f"{name}: max abs err {float(err.max()):.3e} (ref scale {float(ref.abs().max()):.3e}), exceeds tol by {worst:.3e}"
 
 
-@pytest.mark.parametrize("regstage", [0, 8, 1, 3])   # NT: 0 LDS-DMA 128x128 transposed-acc, 8 LDS-DMA 64x128, bit0 register-staged; bit1: register-transposing TN
+# NT: 0 A-stationary kernel where it applies (bf16, K 256/512), else LDS-DMA 128x128 transposed-acc tile kernel; 8192 tile kernel only;
+# 8 LDS-DMA 64x128; bit0 register-staged; bit1: register-transposing TN
+@pytest.mark.parametrize("regstage", [0, 8192, 8, 1, 3])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0), (3000, 768, 256, 0), (1024, 512, 256, 0), (4096, 128, 128, 0)])
+@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0), (3000, 768, 256, 0), (1024, 512, 256, 0), (4096, 128, 128, 0),
+                                       (1000, 256, 512, 1), (333, 512, 128, 0), (900, 256, 256, 2), (50, 512, 512, 0)])
 def test_dense_fwd_bwd(lib, dt, M, K, N, act, regstage):
     lib.ishara_debug_force_regstage(regstage)
     try:
@@ -73,6 +76,31 @@ def _dense_fwd_bwd(lib, dt, M, K, N, act):
     wtol = dict(rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * M ** 0.5)
     close(dW, x.double().t() @ dy.double(), "dense_dW", **wtol)
     close(db, dy.double().sum(0), "dense_db", **wtol)
+
+
+@pytest.mark.parametrize("regstage", [0, 8192, 8])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,N,act", [(1408, 256, 768, 0), (1000, 256, 256, 0), (333, 512, 128, 0), (2048, 512, 256, 1), (130, 64, 64, 0), (77, 256, 64, 2)])
+def test_dense_fwd_residual(lib, dt, M, K, N, act, regstage):
+    """y = act(x W + b) + resid through ishara_op_dense_fwd_ex (the residual epilogues of every NT kernel)."""
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(7 * M + K + N)
+    x = torch.randn(M, K, generator=g).to(tdt)
+    W = torch.randn(K, N, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).to(tdt)
+    xd, Wd, bd, rd = x.cuda().contiguous(), dev(W), dev(b), r.cuda().contiguous()
+    y = torch.empty(M, N, dtype=tdt, device="cuda")
+    sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
+    scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    lib.ishara_debug_force_regstage(regstage)
+    try:
+        _lib.check(lib.ishara_op_dense_fwd_ex(code, _lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), M, K, N, act, scp, stream()))
+    finally:
+        lib.ishara_debug_force_regstage(0)
+    ref = x.double() @ W.to(tdt).double() + b.double()
+    ref = [ref, ref * torch.sigmoid(ref), torch.relu(ref)][act] + r.double()
+    close(y, ref, "dense_fwd_residual", **TOL[dt])
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

@@ -18,22 +18,26 @@ for (M, K, N) in shapes:
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
     scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    r = torch.randn(M, N, device="cuda").bfloat16()
     res = {}
-    variants = {"glds": 0, "glds-noepi": 1 << 4, "glds64": 8, "regstage": 1}
+    variants = {"as": 0, "as-noepi": 1 << 4, "as-nomfma": 2 << 4, "as-nolds": 4 << 4, "as-nolds-nomfma": 6 << 4, "as-onlyepi": 14 << 4, "as-onlyloadA": 15 << 4,
+                "as-nodma": 8 << 4, "tile128": 8192, "glds64": 8}
     for rnd in range(3):
         for name, flag in variants.items():
-            lib.ishara_debug_force_regstage(flag)
-            for _ in range(2):
-                lib.ishara_op_dense_fwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(y), M, K, N, 0, scp, st())
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                lib.ishara_op_dense_fwd(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(y), M, K, N, 0, scp, st())
-            e1.record(); torch.cuda.synchronize()
-            res.setdefault(name, []).append(e0.elapsed_time(e1) / 10 * 1e3)
+            for resid, act in ((None, 0), (r, 0), (None, 1)) if name in ("as", "tile128", "glds64") else ((None, 0),):
+                lib.ishara_debug_force_regstage(flag)
+                run = lambda: lib.ishara_op_dense_fwd_ex(1, _lib.ptr(x), _lib.ptr(W), _lib.ptr(b), _lib.ptr(resid) if resid is not None else None, _lib.ptr(y), M, K, N, act, scp, st())
+                for _ in range(2):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    run()
+                e1.record(); torch.cuda.synchronize()
+                res.setdefault(name + ("+r" if resid is not None else "") + ("+swish" if act else ""), []).append(e0.elapsed_time(e1) / 10 * 1e3)
     lib.ishara_debug_force_regstage(0)
     gb = (M * K * 2 + M * N * 2) / 1e9
-    print(f"M{M} K{K} N{N}: " + "  ".join(f"{k}={min(v):.0f}us" for k, v in res.items()) + f"   [{gb / (min(res['glds']) * 1e-6) / 1e3:.2f} TB/s, includes shadow build+memset]")
+    print(f"M{M} K{K} N{N}: " + "  ".join(f"{k}={min(v):.0f}" for k, v in res.items()) + f" us  [{gb / (min(res['as']) * 1e-6) / 1e3:.2f} TB/s, includes shadow build+memset]")
 
 print("---- TN (wgrad only: dW = x^T dy, + slab reduce + shadow build)")
 for (M, K, N) in [(98304, 256, 512), (98304, 512, 256), (98304, 256, 768)]:
