@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 }
 
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s);
+void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s);
+bool dwconv_bwd_fused_ok(int dt, int C, int k, int padl);
+int launch_dwconv_bwd_fused(int dt, int inop, const void* dy, const void* x, const float* w, void* dx, float* part,
+                            int B, int T, int C, int k, int padl, int max_rows, hipStream_t s);
 
 int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd,
                          const float* gamma, const void* resid, void* dx, float* dgamma, float* dbeta,
@@ -160,10 +164,7 @@ int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mea
 #define LN_BG(TT) switch (G) { case 1: LN_B(TT, 1); break; case 2: LN_B(TT, 2); break; case 4: LN_B(TT, 4); break; case 8: LN_B(TT, 8); break; \
                                case 16: LN_B(TT, 16); break; case 32: LN_B(TT, 32); break; default: LN_B(TT, 64); break; }
     if (dt == DT_BF16) { LN_BG(bf16) } else { LN_BG(float) }
-    if (scratch) {
-        launch_reduce_slabs(scratch, dgamma, C, grid, (size_t)2 * C, s);
-        launch_reduce_slabs(scratch + C, dbeta, C, grid, (size_t)2 * C, s);
-    }
+    if (scratch) launch_reduce_slabs2(scratch, dgamma, C, dbeta, C, grid, (size_t)2 * C, s);
     return LAUNCH_OK();
 }
 size_t layernorm_bwd_scratch_floats(int C) { return (size_t)2048 * 2 * C; }
@@ -356,19 +357,22 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const T* __restrict__ x
                                                          T* __restrict__ y, const T* __restrict__ aux,
                                                          float* __restrict__ ssum, float* __restrict__ ssq,
                                                          int Tn, int C, int padl, int inop, int outop, int flip) {
+    // workgroup = 64 channel quads (256 channels: one wave reads 512 contiguous bytes of a row) x 4 consecutive segments of
+    // one sample: the per-(sample, channel) statistics of the 4 segments are combined in LDS before the atomics
+    __shared__ float sred[4][64][8];
     const int cg = C >> 2;
     const int nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nseg * cg) return;
-    const int c4 = i % cg, seg = i / cg, b = blockIdx.y;
-    const int ch = c4 * 4;
+    const int ncb = (cg + 63) >> 6;
+    const int c4 = (blockIdx.x % ncb) * 64 + (threadIdx.x & 63), seg = (blockIdx.x / ncb) * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const bool live = c4 < cg && seg < nseg;
+    const int ch = min(c4, cg - 1) * 4;
     const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
     float wr[K][4], win[K][4];
 #pragma unroll
     for (int j = 0; j < K; ++j) load4(w + (size_t)(flip ? (K - 1 - j) : j) * C + ch, wr[j]);
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) load4(bias + ch, bv);
-    const int t0 = seg * DWR_SEG, tend = min(Tn, t0 + DWR_SEG);
+    const int t0 = seg * DWR_SEG, tend = live ? min(Tn, t0 + DWR_SEG) : t0;
     // slots 0..K-2 hold inputs t0-padl .. t0-padl+K-2
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) dw_load_in(x, b, t0 - padl + j, Tn, C, Cin, ch, inop, win[j]);
@@ -418,10 +422,19 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const T* __restrict__ x
         }
     }
     if (ssum) {
+        const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            atomicAdd(ssum + (size_t)b * C + ch + e, s1[e]);
-            if (ssq) atomicAdd(ssq + (size_t)b * C + ch + e, s2[e]);
+        for (int e = 0; e < 4; ++e) { sred[sl][cl][e] = live ? s1[e] : 0.f; sred[sl][cl][4 + e] = live ? s2[e] : 0.f; }
+        __syncthreads();
+        if (sl == 0 && c4 < cg) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a += sred[r][cl][e]; q += sred[r][cl][4 + e]; }
+                atomicAdd(ssum + (size_t)b * C + ch + e, a);
+                if (ssq) atomicAdd(ssq + (size_t)b * C + ch + e, q);
+            }
         }
     }
 }
@@ -589,7 +602,7 @@ template <typename T>
 static void launch_dw_reg(int k, const T* x, const float* w, const float* bias, T* y, const T* aux, float* ssum, float* ssq,
                           int B, int Tn, int C, int padl, int inop, int outop, int flip, hipStream_t s) {
     const int nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
-    dim3 grid((nseg * (C / 4) + 255) / 256, B);
+    dim3 grid(((C / 4 + 63) / 64) * ((nseg + 3) / 4), B);
 #define DWR(KK) hipLaunchKernelGGL((dwconv_reg_kernel<T, KK>), grid, dim3(256), 0, s, x, w, bias, y, aux, ssum, ssq, Tn, C, padl, inop, outop, flip)
     switch (k) { case 3: DWR(3); break; case 5: DWR(5); break; case 11: DWR(11); break; default: DWR(15); break; }
 #undef DWR
@@ -746,6 +759,14 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const float* w, void* dx,
                       float* dw, float* dbias, float* scratch, int B, int T, int C, int k, int padl, hipStream_t s) {
     if (dwconv_check(C, k)) return -1;
+    if (scratch && !g_force_dw_lds && dwconv_bwd_fused_ok(dt, C, k, padl)) {
+        // one pass: dx and the per-workgroup partial rows of (dw, dbias), then the row sum
+        const int rows = launch_dwconv_bwd_fused(dt, inop, dy, x, w, dx, scratch, B, T, C, k, padl, DWG_BLOCKS, s);
+        if (rows < 0) return -2;
+        launch_reduce_slabs(scratch, dw, k * C, rows, (size_t)(k + 1) * C, s);
+        if (dbias) launch_reduce_slabs(scratch + (size_t)k * C, dbias, C, rows, (size_t)(k + 1) * C, s);
+        return LAUNCH_OK();
+    }
     const int outop = inop == DWIN_SWISH ? OUT_DSWISH : (inop == DWIN_GLU ? OUT_DGLU : OUT_NONE);
     const bool reg = dw_reg_ok(C, k) && !g_force_dw_lds;
     // data grad: correlation with flipped taps, left pad k-1-padl; then through the input op
@@ -807,13 +828,23 @@ __global__ __launch_bounds__(256) void sample_reduce_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; mu[e] = (act && mean) ? mean[chunk * 8 + e] : 0.f; rs[e] = (act && mean) ? rstd[chunk * 8 + e] : 1.f; }
         if (act) {
-            for (int t = tb + rl; t < te; t += RL) {
-                float d[8], o[8];
-                const size_t off = ((size_t)b * Tn + t) * C + chunk * 8;
-                load8(dy + off, d);
-                if (other) load8(other + off, o);
+            // four rows (eight 16-byte loads with `other`) in flight per lane
+            for (int t0 = tb + rl; t0 < te; t0 += 4 * RL) {
+                float d[4][8], o[4][8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { a[e] += d[e]; if (other) q[e] += d[e] * ((o[e] - mu[e]) * rs[e]); }
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * RL;
+                    const size_t off = ((size_t)b * Tn + min(t, te - 1)) * C + chunk * 8;
+                    load8(dy + off, d[u]);
+                    if (other) load8(other + off, o[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (t0 + u * RL < te) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { a[e] += d[u][e]; if (other) q[e] += d[u][e] * ((o[u][e] - mu[e]) * rs[e]); }
+                    }
+                }
             }
         }
 #pragma unroll

@@ -1293,7 +1293,65 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
+void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s);
+// Narrow slabs (n <= 2048 columns: LayerNorm dgamma/dbeta, bias gradients): a workgroup of 1024 threads owns 32 columns;
+// thread (cq = tid&7, sl = tid>>3) sums the slabs sl, sl+128, ... of column quad cq with 8 loads in flight, the 128 slab
+// lanes are combined by wave shuffles + LDS, and ONE thread adds the total to out: no atomics, one launch for two
+// outputs (columns [0, n0) -> out0, [n0, n) -> out1).
+__global__ __launch_bounds__(1024) void reduce_slabs_cols_kernel(const float* __restrict__ slab, float* __restrict__ out0, float* __restrict__ out1,
+                                                                 int n0, int n, int splits, size_t stride) {
+    __shared__ float4 red[16][8];
+    const int tid = threadIdx.x, cq = tid & 7, sl = tid >> 3;
+    const int col = blockIdx.x * 32 + cq * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < n) {
+        for (int s0 = sl; s0 < splits; s0 += 128 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sidx = s0 + 128 * u;
+                v[u] = sidx < splits ? *reinterpret_cast<const float4*>(slab + (size_t)sidx * stride + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if ((tid & 63) < 8) red[tid >> 6][cq] = acc;
+    __syncthreads();
+    if (tid < 8 && col < n) {
+        float4 t = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) { t.x += red[w][tid].x; t.y += red[w][tid].y; t.z += red[w][tid].z; t.w += red[w][tid].w; }
+        float* dst = col < n0 ? out0 + col : out1 + (col - n0);      // parameter blocks of the flat gradient are only 4-byte aligned
+        dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;
+    }
+}
+
+static bool reduce_cols_ok(const float* slab, const float* out0, const float* out1, int n0, int n, size_t stride) {
+    (void)out0; (void)out1;
+    return n <= 2048 && n % 4 == 0 && n0 % 4 == 0 && stride % 4 == 0 && ((uintptr_t)slab) % 16 == 0;
+}
+
+// out0[0..n0) += column sums of slab[:, 0..n0), out1[0..n1) += column sums of slab[:, n0..n0+n1)   (slab rows `stride` floats apart)
+void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s) {
+    if (reduce_cols_ok(slab, out0, out1, n0, n0 + n1, stride)) {
+        hipLaunchKernelGGL(reduce_slabs_cols_kernel, dim3((n0 + n1 + 31) / 32), dim3(1024), 0, s, slab, out0, out1, n0, n0 + n1, splits, stride);
+        return;
+    }
+    launch_reduce_slabs(slab, out0, n0, splits, stride, s);
+    if (out1 && n1 > 0) launch_reduce_slabs(slab + n0, out1, n1, splits, stride, s);
+}
+
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s) {
+    if (reduce_cols_ok(slab, out, nullptr, n, n, stride)) {
+        hipLaunchKernelGGL(reduce_slabs_cols_kernel, dim3((n + 31) / 32), dim3(1024), 0, s, slab, out, (float*)nullptr, n, n, splits, stride);
+        return;
+    }
     const int gx = (n + 1023) / 1024;
     int gy = 1;                                            // split groups: enough workgroups to fill the chip
     while (gx * gy < 512 && gy * 16 <= splits) gy *= 2;
