@@ -28,7 +28,7 @@ DEVI uint32_t pk2(float lo, float hi) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
+__global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
                                                             bf16* __restrict__ o, float* __restrict__ lse, int H, int Tn, float scale, DropSpec drop) {
     constexpr int KS = DH / 32;      // MFMA k-steps over the head dimension
     constexpr int DT = DH / 16;      // 16-wide output (dv) tiles
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
         const bf16* Kc = Ks[ch & 1];
         const bf16* Vc = Vs[ch & 1];
         const int key0 = ch * AF_KC;
+        const bool partial = key0 + AF_KC > Tn;      // only the last chunk needs per-key bounds masks
         // ---- S^T tiles: 4 key tiles x 2 query tiles
         f32x4 sacc[4][2];
 #pragma unroll
@@ -118,13 +119,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (key0 + 16 * kt + 4 * g + r >= Tn) sacc[kt][t][r] = -1e30f;
+                    if (partial && key0 + 16 * kt + 4 * g + r >= Tn) sacc[kt][t][r] = -1e30f;
                     mx = fmaxf(mx, sacc[kt][t][r]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m_run[t], mx);
-            const float corr = exp2f((m_run[t] - mn) * cs);
+            const float corr = __builtin_amdgcn_exp2f((m_run[t] - mn) * cs);      // raw v_exp_f32: exp2f() adds a 6-instruction denormal-range wrapper
+            const float mnc = -mn * cs;
             m_run[t] = mn;
             l_run[t] *= corr;
 #pragma unroll
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2f((sacc[kt][t][r] - mn) * cs);
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], cs, mnc));
                     l_run[t] += pv;
                     float pd = pv;
                     if (drop.thr) pd = rng_keep(rkey, (uint32_t)(key0 + 16 * kt + 4 * g + r), drop.thr) ? pv * drop.scale : 0.f;
@@ -215,7 +217,7 @@ DEVI bf16x8 pack8(const float (&a)[4], const float (&b)[4]) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
+__global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dq_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
                                                                const bf16* __restrict__ o, const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                                int H, int Tn, float scale, DropSpec drop) {
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
         const bf16* Kc = Ks[ch & 1];
         const bf16* Vc = Vs[ch & 1];
         const int key0 = ch * AF_KC;
+        const bool partial = key0 + AF_KC > Tn;      // only the last chunk needs per-key bounds masks
         bf16x8 dsb[2][2];
         {
             f32x4 sacc[4][2], dpa[4][2];
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = key0 + 16 * kt + 4 * g + r;
-                        const float pv = key < Tn ? exp2f(sacc[kt][t][r] * cs - lsl[t]) : 0.f;
+                        const float pv = (!partial || key < Tn) ? __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], cs, -lsl[t])) : 0.f;
                         float dp = dpa[kt][t][r];
                         if (drop.thr) dp = rng_keep(rkey, (uint32_t)key, drop.thr) ? dp * drop.scale : 0.f;
                         ds[kt][r] = pv * (dp - dlt[t]) * scale;
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
+__global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                 const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                                 int H, int Tn, float scale, DropSpec drop) {
@@ -440,65 +443,62 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __re
         const float* Dlc = Dl[ch & 1];
         const uint32_t* Rc = Rk[ch & 1];
         const int q0 = ch * AF_KC;
-        bf16x8 pdb[2][2], dsb[2][2];
-        {
-            f32x4 sacc[4][2], dpa[4][2];
+        const bool partial = q0 + AF_KC > Tn;
+        // 32 queries (ks) at a time: scores / dP for both key tiles, the elementwise pass, then straight into the dV / dK
+        // products of those 32 queries -- keeps ~70 fewer registers live than doing all 64 queries at once (3 waves / SIMD)
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                bf16x8 qfr[KS], dfr[KS];
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    qfr[s] = *reinterpret_cast<const bf16x8*>(Qc + (16 * qt + c) * KLD + 32 * s + 8 * g);
-                    dfr[s] = *reinterpret_cast<const bf16x8*>(Dc + (16 * qt + c) * KLD + 32 * s + 8 * g);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    sacc[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    dpa[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        sacc[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[s], kf[t][s], sacc[qt][t], 0, 0, 0);
-                        dpa[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[s], vf[t][s], dpa[qt][t], 0, 0, 0);
-                    }
-                }
-            }
-            // element (qt, t, r): query q0 + 16qt + 4g + r, key kbase + 16t + c
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 pdb[2], dsb[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const uint32_t key = (uint32_t)(kbase + 16 * t + c);
-                float pd[4][4], ds[4][4];
+                f32x4 sacc[2], dpa[2];
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
+                for (int hq = 0; hq < 2; ++hq) {
+                    const int qt = 2 * ks + hq;
+                    sacc[hq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dpa[hq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(Qc + (16 * qt + c) * KLD + 32 * s + 8 * g);
+                        const bf16x8 dfr = *reinterpret_cast<const bf16x8*>(Dc + (16 * qt + c) * KLD + 32 * s + 8 * g);
+                        sacc[hq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[t][s], sacc[hq], 0, 0, 0);
+                        dpa[hq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[t][s], dpa[hq], 0, 0, 0);
+                    }
+                }
+                // element (hq, r): query q0 + 32ks + 16hq + 4g + r, key kbase + 16t + c
+                const uint32_t key = (uint32_t)(kbase + 16 * t + c);
+                float pd[2][4], ds[2][4];
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int ql = 16 * qt + 4 * g + r;
-                        const float pv = (q0 + ql < Tn) ? exp2f(sacc[qt][t][r] * cs - Lc[ql]) : 0.f;
-                        float dp = dpa[qt][t][r], pdv = pv;
+                        const int ql = 32 * ks + 16 * hq + 4 * g + r;
+                        const float pv = (!partial || q0 + ql < Tn) ? __builtin_amdgcn_exp2f(fmaf(sacc[hq][r], cs, -Lc[ql])) : 0.f;
+                        float dp = dpa[hq][r], pdv = pv;
                         if (drop.thr) {
                             const bool keep = rng_keep(Rc[ql], key, drop.thr);
                             dp = keep ? dp * drop.scale : 0.f;
                             pdv = keep ? pv * drop.scale : 0.f;
                         }
-                        pd[qt][r] = pdv;
-                        ds[qt][r] = pv * (dp - Dlc[ql]) * scale;
+                        pd[hq][r] = pdv;
+                        ds[hq][r] = pv * (dp - Dlc[ql]) * scale;
                     }
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) { pdb[t][ks] = pack8(pd[2 * ks], pd[2 * ks + 1]); dsb[t][ks] = pack8(ds[2 * ks], ds[2 * ks + 1]); }
+                pdb[t] = pack8(pd[0], pd[1]);
+                dsb[t] = pack8(ds[0], ds[1]);
             }
-        }
-        // dV^T[dv][key] += dO^T[dv][q].(P o D)[q][key] ; dK^T[dh][key] += Q^T[dh][q].dS[q][key]
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            // dV^T[dv][key] += dO^T[dv][q].(P o D)[q][key] ; dK^T[dh][key] += Q^T[dh][q].dS[q][key]
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 const bf16x8 dtf = trfrag(Dc, KLD, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
                 const bf16x8 qtf = trfrag(Qc, KLD, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    adv[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtf, pdb[t][ks], adv[d][t], 0, 0, 0);
-                    adk[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsb[t][ks], adk[d][t], 0, 0, 0);
+                    adv[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtf, pdb[t], adv[d][t], 0, 0, 0);
+                    adk[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsb[t], adk[d][t], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (more) DKV_LSTORE((ch + 1) & 1);
         __syncthreads();
     }
