@@ -1,142 +1,218 @@
 // CTC loss + gradient (conv-hybrid-model.ipynb c6:1-13 -> tf.nn.ctc_loss semantics with
 // blank = last class, logit_length = T) and the greedy decoder (c8:4-12).
 //
-// One 512-thread workgroup per sample.  The lattice has S = 2*len+1 <= 2L+1 states;
-// phase 1 runs the alpha recursion (threads 0..S-1, one barrier per frame, state vector
-// double-buffered in LDS), phase 2 the beta recursion, folding alpha+beta into state
-// posteriors in place in the fp32 workspace [B,T,S]; phase 3 scatters posteriors to
-// classes in parallel over (t, c):  dlogits = grad_scale * (softmax - posterior).
+// One workgroup per sample; the lattice has S = 2*len+1 <= 2L+1 states (see ctc_scaled_kernel).
 #include "kernels.h"
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
-#define CTC_NEG (-1e30)
 
-// log(e^a + e^b + e^c) with the running state in fp64 and the transcendentals in fp32: the
-// lattice values reach ~-1500 at T=384 where an fp32 ulp is 1.2e-4 and the drift over T steps
-// reaches 1e-3 relative in the posteriors; fp64 add/max keeps the drift at the 1e-6 level while
-// exp/log only ever see small-magnitude differences.
+static inline int ctc_ns(int L) { return (2 * L + 1 + 63) / 64; }            // lattice states per lane of the recursion wave
+size_t ctc_workspace_floats(int B, int T, int L) { return 4 * (size_t)B * T * 64 * ctc_ns(L); }   // two fp64 lattices [B][T][64*NS]: alpha, beta sums
+
+#define CTC_NEG (-1e30)
+// log(e^a + e^b + e^c) with the running state in fp64 and the transcendentals in fp32: the lattice values reach ~-1700 at
+// T=384 where an fp32 ulp is 1.2e-4 and the drift over T frames reaches 1e-3 relative in the posteriors; fp64 add/max keeps
+// the drift at the 1e-6 level while exp/log only ever see small-magnitude differences.  (A scaled PROBABILITY-space
+// recursion is not an option: the state vector of one frame spans > 250 decades on random logits, tools/ notes in DESIGN.md.)
 DEVI double lse3(double a, double b, double c) {
     const double m = fmax(a, fmax(b, c));
     if (m <= -1e29) return CTC_NEG;
     const float sum = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
     return m + (double)__logf(sum);
 }
+DEVI double shfl_up_d(double v, int d) { return __shfl_up(v, d, 64); }
+DEVI double shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
 
-size_t ctc_workspace_floats(int B, int T, int L) { return 2 * (size_t)B * T * (2 * L + 1); }   // fp64 lattice
-
-__global__ __launch_bounds__(512) void ctc_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+// ---------------------------------------------------------------------------------------------------------------
+// One 256-thread workgroup per sample:
+//   phase 0 (all threads)  lse[t] = logsumexp(logits[t]); extended label sequence
+//   phase 1 (wave 0)       alpha recursion in log space: the S = 2*len+1 states live in REGISTERS, NS consecutive states
+//                          per lane; the s-1 / s-2 neighbours of a lane's first states come from the previous lane by two
+//                          shuffles per frame.  No barrier and no LDS on the dependency chain (the previous kernel
+//                          spent a workgroup barrier and an L2 round trip per frame: 0.9 ms at T=384); the emission
+//                          log-probabilities are gathered 8 frames ahead of the chain.
+//   phase 1' (wave 1)      beta recursion the same way, CONCURRENTLY with alpha on another SIMD (the two chains are
+//                          independent); it stores bsum_t[s] = log sum of the successors' betas
+//   phase 2 (all threads)  state posteriors exp(alpha + bsum - logp) scatter-added to classes in LDS, one frame per wave at
+//                          a time; dlogits = grad_scale * (softmax - posterior)
+// ---------------------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                   int Tn, int C, int L, int blank, float* __restrict__ nll,
                                                   float* __restrict__ dlogits, float grad_scale, double* __restrict__ ws) {
-    extern __shared__ double shd[];
-    const int Smax = 2 * L + 1;
-    double* buf = shd;                                   // [2][Smax + 2]
-    float* lse = reinterpret_cast<float*>(buf + 2 * (Smax + 2));   // [Tn]
-    int* ext = reinterpret_cast<int*>(lse + Tn);         // [Smax]
+    constexpr int SP = 64 * NS;
+    extern __shared__ float shf[];
+    float* lse = shf;                                   // [Tn]
+    int* ext = reinterpret_cast<int*>(lse + Tn);        // [SP]
     __shared__ int s_len;
-    __shared__ double s_logp;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const float* lg = logits + (size_t)b * Tn * C;
     const int64_t* lab = labels + (size_t)b * L;
-    double* wsb = ws + (size_t)b * Tn * Smax;
+    double* Gw = ws + (size_t)b * 2 * Tn * SP;          // [Tn][SP] alpha
+    double* Hw = Gw + (size_t)Tn * SP;                  // [Tn][SP] bsum
+    __shared__ double s_logp;
 
     if (tid == 0) { int n = 0; for (int i = 0; i < L; ++i) n += (lab[i] != blank) ? 1 : 0; s_len = n; }
-    for (int t = tid; t < Tn; t += blockDim.x) {
+    for (int t = tid; t < Tn; t += 256) {
         float m = -1e30f;
         for (int c = 0; c < C; ++c) m = fmaxf(m, lg[(size_t)t * C + c]);
         float a = 0.f;
         for (int c = 0; c < C; ++c) a += expf(lg[(size_t)t * C + c] - m);
         lse[t] = m + logf(a);
     }
-    for (int s = tid; s < Smax; s += blockDim.x) ext[s] = (s & 1) ? (int)lab[s >> 1] : blank;
+    for (int s = tid; s < SP; s += 256) ext[s] = (s < 2 * L + 1 && (s & 1)) ? (int)lab[s >> 1] : blank;
     __syncthreads();
     const int len = s_len, S = 2 * len + 1;
-    const int s = tid;
-    const bool act = s < S;
-    const int my = act ? ext[s] : blank;
-    const bool skip_ok = act && s >= 2 && my != blank && my != ext[s - 2];          // s-2 -> s
-    const bool skip_fw = act && s + 2 < S && ext[s + 2] != blank && ext[s + 2] != my;   // s -> s+2 (beta)
 
-    // ---- phase 1: alpha ----
-    {
-        double* p0 = buf + 2;                // index -2..Smax-1
-        double* p1 = buf + (Smax + 2) + 2;
-        if (tid < 2) { buf[tid] = CTC_NEG; buf[(Smax + 2) + tid] = CTC_NEG; }
-        double a = CTC_NEG;
-        if (act && (s == 0 || (s == 1 && len > 0))) a = (double)(lg[my] - lse[0]);
-        if (s < Smax) { p0[s] = a; wsb[s] = a; }
-        __syncthreads();
-        for (int t = 1; t < Tn; ++t) {
-            double* prev = (t & 1) ? p0 : p1;
-            double* cur = (t & 1) ? p1 : p0;
-            double v = CTC_NEG;
-            if (act) {
-                const double x2 = skip_ok ? prev[s - 2] : CTC_NEG;
-                v = lse3(prev[s], prev[s - 1], x2);
-                if (v > -1e29) v += (double)(lg[(size_t)t * C + my] - lse[t]);
+    if (tid < 128) {
+        const int wave = tid >> 6;
+        bool act[NS], skip_bw[NS], skip_fw[NS];
+        int my[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int s = NS * lane + k;
+            my[k] = ext[s];
+            act[k] = s < S;
+            skip_bw[k] = act[k] && s >= 2 && my[k] != blank && my[k] != ext[s - 2];                   // s-2 -> s
+            skip_fw[k] = s + 2 < S && ext[s + 2] != blank && ext[s + 2] != my[k];                     // s -> s+2
+        }
+        float em[8][NS], emn[8][NS];
+        auto gather = [&](int t0, int dir, float (&dst)[8][NS]) {      // frames t0, t0 + dir, .., t0 + 7 dir
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = min(max(t0 + dir * u, 0), Tn - 1);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) dst[u][k] = lg[(size_t)t * C + my[k]] - lse[t];
             }
-            if (s < Smax) { cur[s] = v; wsb[(size_t)t * Smax + s] = v; }
-            __syncthreads();
+        };
+      if (wave == 0) {
+        // ---- alpha ----
+        double a[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int s = NS * lane + k;
+            a[k] = (act[k] && (s == 0 || (s == 1 && len > 0))) ? (double)(lg[my[k]] - lse[0]) : CTC_NEG;
+            Gw[s] = a[k];
         }
-        if (tid == 0) {
-            double* last = ((Tn - 1) & 1) ? p1 : p0;
-            const double aL = last[S - 1], aL1 = (len > 0) ? last[S - 2] : CTC_NEG;
-            const double lp = lse3(aL, aL1, CTC_NEG);
-            s_logp = lp;
-            nll[b] = (float)(-lp);
-        }
-        __syncthreads();
-    }
-    const double logp = s_logp;
-    // ---- phase 2: beta, posteriors written over alpha ----
-    {
-        double* p0 = buf;                    // index 0..Smax+1 (two trailing pads)
-        double* p1 = buf + (Smax + 2);
-        if (tid < 2) { p0[Smax + tid] = CTC_NEG; p1[Smax + tid] = CTC_NEG; }
-        __syncthreads();
-        double bt = CTC_NEG;
-        const int tl = Tn - 1;
-        if (act && (s == S - 1 || (s == S - 2 && len > 0))) bt = (double)(lg[(size_t)tl * C + my] - lse[tl]);
-        if (s < Smax) {
-            p0[s] = bt;
-            const double al = wsb[(size_t)tl * Smax + s];
-            const double lpy = (double)(lg[(size_t)tl * C + my] - lse[tl]);
-            wsb[(size_t)tl * Smax + s] = (act && al > -1e29 && bt > -1e29) ? (double)__expf((float)(al + bt - lpy - logp)) : 0.0;
-        }
-        __syncthreads();
-        for (int t = Tn - 2, it = 1; t >= 0; --t, ++it) {
-            double* nxt = (it & 1) ? p0 : p1;
-            double* cur = (it & 1) ? p1 : p0;
-            double v = CTC_NEG;
-            double lpy = 0.0;
-            if (act) {
-                lpy = (double)(lg[(size_t)t * C + my] - lse[t]);
-                const double x2 = skip_fw ? nxt[s + 2] : CTC_NEG;
-                const double x1 = (s + 1 < S) ? nxt[s + 1] : CTC_NEG;
-                v = lse3(nxt[s], x1, x2);
-                if (v > -1e29) v += lpy;
+        // the emission log-probabilities of frame group g+1 are gathered while group g runs (register double buffer): the
+        // serial chain never waits on memory
+        gather(1, 1, em);
+        for (int t0 = 1; t0 < Tn; t0 += 8) {
+            if (t0 + 8 < Tn) gather(t0 + 8, 1, emn);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u;
+                if (t < Tn) {
+                    double up1 = shfl_up_d(a[NS - 1], 1);
+                    double up2 = NS >= 2 ? shfl_up_d(a[NS >= 2 ? NS - 2 : 0], 1) : shfl_up_d(a[0], 2);
+                    if (lane == 0) { up1 = CTC_NEG; up2 = CTC_NEG; }
+                    if (NS == 1 && lane == 1) up2 = CTC_NEG;
+                    double n[NS];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const double a1 = k >= 1 ? a[k - 1] : up1;
+                        const double a2 = k >= 2 ? a[k - 2] : (k == 1 ? up1 : up2);
+                        double v = act[k] ? lse3(a[k], a1, skip_bw[k] ? a2 : CTC_NEG) : CTC_NEG;
+                        if (v > -1e29) v += (double)em[u][k];
+                        n[k] = v;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) { a[k] = n[k]; Gw[(size_t)t * SP + NS * lane + k] = n[k]; }
+                }
             }
-            if (s < Smax) {
-                cur[s] = v;
-                const double al = wsb[(size_t)t * Smax + s];
-                wsb[(size_t)t * Smax + s] = (act && al > -1e29 && v > -1e29) ? (double)__expf((float)(al + v - lpy - logp)) : 0.0;
-            }
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) em[u][k] = emn[u][k];
         }
+        // log p(y | x) = logsumexp(alpha[S-1], alpha[S-2]): both live in (at most two) lanes; reduce max then sum over the wave
+        double logp;
+        {
+            double cand = CTC_NEG, cand2 = CTC_NEG;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = NS * lane + k;
+                if (s == S - 1) cand = a[k];
+                if (s == S - 2 && len > 0) cand2 = a[k];
+            }
+            double m = fmax(cand, cand2);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+            float e = 0.f;
+            if (m > -1e29) e = ((cand > -1e29) ? __expf((float)(cand - m)) : 0.f) + ((cand2 > -1e29) ? __expf((float)(cand2 - m)) : 0.f);
+            e = wave_sum(e);
+            logp = (m > -1e29) ? m + (double)__logf(e) : CTC_NEG;
+            if (lane == 0) { nll[b] = (float)(-logp); s_logp = logp; }
+        }
+      } else {
+        // ---- beta (with emission): bt = beta_{t+1}; stores bsum_t[s] = logsumexp of the successors' betas ----
+        double bt[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) bt[k] = CTC_NEG;
+        gather(Tn - 1, -1, em);
+        for (int tb = Tn - 1; tb >= 0; tb -= 8) {
+            if (tb - 8 >= 0) gather(tb - 8, -1, emn);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = tb - u;
+                if (t >= 0) {
+                    double bsum[NS];
+                    if (t == Tn - 1) {
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {
+                            const int s = NS * lane + k;
+                            bsum[k] = (act[k] && (s == S - 1 || (s == S - 2 && len > 0))) ? 0.0 : CTC_NEG;
+                        }
+                    } else {
+                        double dn1 = shfl_down_d(bt[0], 1);
+                        double dn2 = NS >= 2 ? shfl_down_d(bt[NS >= 2 ? 1 : 0], 1) : shfl_down_d(bt[0], 2);
+                        if (lane == 63) { dn1 = CTC_NEG; dn2 = CTC_NEG; }
+                        if (NS == 1 && lane == 62) dn2 = CTC_NEG;
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {
+                            const double b1 = k + 1 < NS ? bt[k + 1] : dn1;
+                            const double b2 = k + 2 < NS ? bt[k + 2] : (k + 1 < NS ? dn1 : dn2);
+                            bsum[k] = act[k] ? lse3(bt[k], b1, skip_fw[k] ? b2 : CTC_NEG) : CTC_NEG;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        Hw[(size_t)t * SP + NS * lane + k] = bsum[k];
+                        bt[k] = bsum[k] > -1e29 ? bsum[k] + (double)em[u][k] : CTC_NEG;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) em[u][k] = emn[u][k];
+        }
+      }
     }
     __threadfence_block();
     __syncthreads();
-    // ---- phase 3: class posteriors and gradient, parallel over (t, c) ----
+    // ---- phase 3: state posteriors -> class posteriors by LDS scatter-add (one frame per wave at a time: O(T*S) work;
+    // a (frame, class) thread looping over the states was O(T*C*S) and took longer than both recursions), then the gradient
     if (dlogits) {
+        __shared__ float cls[4][64];
+        const double logp = s_logp;
         float* dl = dlogits + (size_t)b * Tn * C;
-        const int cl = tid & 63, ts = tid >> 6;        // 8 frames in flight x 64 class lanes
-        for (int t = ts; t < Tn; t += 8) {
-            if (cl < C) {
-                const double* g = wsb + (size_t)t * Smax;
-                double acc = 0.0;
-                if (cl == blank) { for (int s2 = 0; s2 < S; s2 += 2) acc += g[s2]; }
-                else { for (int s2 = 1; s2 < S; s2 += 2) if (ext[s2] == cl) acc += g[s2]; }
-                const float sm = expf(lg[(size_t)t * C + cl] - lse[t]);
-                dl[(size_t)t * C + cl] = grad_scale * (sm - (float)acc);
+        const int wv = tid >> 6;
+        for (int t = wv; t < Tn; t += 4) {
+            cls[wv][lane] = 0.f;
+            const double* ga = Gw + (size_t)t * SP;
+            const double* gb = Hw + (size_t)t * SP;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int s = lane + 64 * k;                  // strided: coalesced 512-byte reads of the lattice rows
+                if (s < S) {
+                    const double al = ga[s], bs = gb[s];
+                    if (al > -1e29 && bs > -1e29 && logp > -1e29) atomicAdd(&cls[wv][ext[s]], __expf((float)(al + bs - logp)));
+                }
+            }
+            if (lane < C) {
+                const float sm = expf(lg[(size_t)t * C + lane] - lse[t]);
+                dl[(size_t)t * C + lane] = grad_scale * (sm - cls[wv][lane]);
             }
         }
     }
@@ -145,8 +221,12 @@ __global__ __launch_bounds__(512) void ctc_kernel(const float* __restrict__ logi
 int launch_ctc(const float* logits, const int64_t* labels, int B, int T, int C, int L, int blank,
                float* nll, float* dlogits, float grad_scale, float* ws, hipStream_t s) {
     if (2 * L + 1 > 512 || C > 64) { ishara_set_error("ctc: L=%d (max 255) or C=%d (max 64) unsupported", L, C); return -1; }
-    const size_t shmem = (size_t)(2 * (2 * L + 3)) * sizeof(double) + (size_t)T * sizeof(float) + (size_t)(2 * L + 1) * sizeof(int);
-    hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(512), shmem, s, logits, labels, T, C, L, blank, nll, dlogits, grad_scale, reinterpret_cast<double*>(ws));
+    const int ns = ctc_ns(L);
+    const size_t shmem = (size_t)T * sizeof(float) + (size_t)64 * ns * sizeof(int);
+#define CTC_L(NS) hipLaunchKernelGGL(ctc_kernel<NS>, dim3(B), dim3(256), shmem, s, logits, labels, T, C, L, blank, nll, dlogits, grad_scale, reinterpret_cast<double*>(ws))
+    switch (ns) { case 1: CTC_L(1); break; case 2: CTC_L(2); break; case 3: CTC_L(3); break; case 4: CTC_L(4); break;
+                  case 5: CTC_L(5); break; case 6: CTC_L(6); break; case 7: CTC_L(7); break; default: CTC_L(8); break; }
+#undef CTC_L
     return LAUNCH_OK();
 }
 

@@ -1115,7 +1115,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define TR_STAGE 16384          // A 32 rows x 256 B + B 32 rows x 256 B
 #define TR_ROWS 32
-#define TR_NSTAGE 4
+#define TR_NSTAGE 4          // measured: 3 stages (3 workgroups/CU) 116 us, 4 stages (2/CU) 90 us, 5 stages (80 KB, 1-2/CU) 94 us per wgrad
 
 DEVI int tr_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
@@ -1181,7 +1181,8 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(const bf16* __restrict_
     for (int mc = 0; mc < nmc_run; ++mc) {
         // 4 DMA per wave per tile; tiles mc+1, mc+2 may stay in flight
         const int ahead = min(nmc - 1 - mc, TR_NSTAGE - 2);
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
