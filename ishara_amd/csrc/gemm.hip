@@ -1144,7 +1144,7 @@ DEVI bf16x8 tr_frag(const char* tile, int lb, int s, int lane) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                          float* __restrict__ out, float* __restrict__ dbias,
                                                          int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, int dbg) {
     __shared__ __attribute__((aligned(16))) char smem[TR_NSTAGE * TR_STAGE];
@@ -1174,49 +1174,63 @@ __global__ __launch_bounds__(256) void gemm_tn_tr_kernel(const bf16* __restrict_
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-    for (int st = 0; st < TR_NSTAGE - 1; ++st)
-        if (st < nmc && !(dbg & 4)) tr_issue(A, B, Ka, Nb, k0, n0, m_beg + st * TR_ROWS, smem + st * TR_STAGE, wid, lane);
-    const int nmc_run = (dbg & 16) ? 0 : nmc;
-    for (int mc = 0; mc < nmc_run; ++mc) {
-        // 4 DMA per wave per tile; tiles mc+1, mc+2 may stay in flight
-        const int ahead = min(nmc - 1 - mc, TR_NSTAGE - 2);
-        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (mc + TR_NSTAGE - 1 < nmc && !(dbg & 4))
-            tr_issue(A, B, Ka, Nb, k0, n0, m_beg + (mc + TR_NSTAGE - 1) * TR_ROWS, smem + ((mc + TR_NSTAGE - 1) % TR_NSTAGE) * TR_STAGE, wid, lane);
-        const char* sa = smem + (mc % TR_NSTAGE) * TR_STAGE;
+    // Software pipeline over the 32-row stages (ring of 4 x 16 KB): at iteration mc the MFMAs of stage mc run from
+    // fragments already in registers while the transposing LDS reads of stage mc+1 are in flight, and stages mc+2 .. mc+4
+    // are in flight from L2/HBM (the slot of stage mc is free as soon as every wave has passed this iteration's barrier,
+    // because its fragments were read during iteration mc-1).
+    auto issue_stage = [&](int st) {
+        if (st < nmc && !(dbg & 4)) tr_issue(A, B, Ka, Nb, k0, n0, m_beg + st * TR_ROWS, smem + (st % TR_NSTAGE) * TR_STAGE, wid, lane);
+    };
+    auto read_frags = [&](int st, bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+        const char* sa = smem + (st % TR_NSTAGE) * TR_STAGE;
         const char* sb = sa + 8192;
 #pragma unroll
-        for (int s = 0; s < 1; ++s) {
-            bf16x8 a[4], b[4];
+        for (int i = 0; i < 4; ++i) a[i] = (dbg & 2) ? bf16x8{} : tr_frag(sa, wr * 4 + i, 0, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = (dbg & 2) ? bf16x8{} : tr_frag(sa, wr * 4 + i, s, lane);
+        for (int j = 0; j < 4; ++j) b[j] = (dbg & 2) ? bf16x8{} : tr_frag(sb, wc * 4 + j, 0, lane);
+    };
+    const int nmc_run = (dbg & 16) ? 0 : nmc;
+    bf16x8 a_cur[4], b_cur[4], a_nxt[4], b_nxt[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = (dbg & 2) ? bf16x8{} : tr_frag(sb, wc * 4 + j, s, lane);
-            if (want_bias) {
+    for (int st = 0; st < TR_NSTAGE; ++st) issue_stage(st);
+    if (nmc_run > 0) {
+        // stage 0 landed: its 4 DMA are the oldest of up to 16
+        if (nmc >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, a_cur, b_cur);
+    }
+    for (int mc = 0; mc < nmc_run; ++mc) {
+        // stage mc+1 landed; the DMA of stages mc+2, mc+3 (4 per wave each) may stay in flight
+        const int younger = min(nmc - 1, mc + 3) - (mc + 1);        // stages issued after mc+1 so far
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's reads of stage mc are in registers
+        __builtin_amdgcn_s_barrier();
+        issue_stage(mc + TR_NSTAGE);                                 // into the slot of stage mc
+        if (mc + 1 < nmc_run) read_frags(mc + 1, a_nxt, b_nxt);
+        if (want_bias) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                float t = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) t += (float)b[j][e];
-                    csum[j] += t;
-                }
-            }
-            if (!(dbg & 1)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][0][0] += (float)a[i][0] + (float)b[i][0];
+                for (int e = 0; e < 8; ++e) t += (float)b_cur[j][e];
+                csum[j] += t;
             }
         }
+        if (!(dbg & 1)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0][0] += (float)a_cur[i][0] + (float)b_cur[i][0];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a_cur[i] = a_nxt[i]; b_cur[i] = b_nxt[i]; }
     }
 
     // ---- write this split's 128x128 partial to its fp32 slab: each wave transposes its 64x64 accumulator block through
@@ -1295,22 +1309,24 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s);
-// Narrow slabs (n <= 2048 columns: LayerNorm dgamma/dbeta, bias gradients): a workgroup of 1024 threads owns 32 columns;
-// thread (cq = tid&7, sl = tid>>3) sums the slabs sl, sl+128, ... of column quad cq with 8 loads in flight, the 128 slab
-// lanes are combined by wave shuffles + LDS, and ONE thread adds the total to out: no atomics, one launch for two
-// outputs (columns [0, n0) -> out0, [n0, n) -> out1).
-__global__ __launch_bounds__(1024) void reduce_slabs_cols_kernel(const float* __restrict__ slab, float* __restrict__ out0, float* __restrict__ out1,
-                                                                 int n0, int n, int splits, size_t stride) {
-    __shared__ float4 red[16][8];
+// Slab sums without atomics: a workgroup owns 32 columns; thread (cq = tid&7, sl = tid>>3) sums the slabs sl, sl+SL, ... of
+// column quad cq with 8 loads in flight, the SL slab lanes are combined by wave shuffles + LDS, and ONE thread adds the
+// total to out; one launch serves two outputs (columns [0, n0) -> out0, [n0, n) -> out1).  Same-address atomics were the
+// whole cost of the previous reducer (2-way 80 us, 4-way 83 us, 8-way 106 us per wgrad including the GEMM).
+template <int SL>     // slab lanes per workgroup: 128 (narrow slabs: 1024 threads own 32 columns) or 32 (wide slabs: 256 threads)
+__global__ __launch_bounds__(8 * SL) void reduce_slabs_cols_kernel(const float* __restrict__ slab, float* __restrict__ out0, float* __restrict__ out1,
+                                                                   int n0, int n, int splits, size_t stride) {
+    constexpr int NWV = SL / 8;            // waves
+    __shared__ float4 red[NWV][8];
     const int tid = threadIdx.x, cq = tid & 7, sl = tid >> 3;
     const int col = blockIdx.x * 32 + cq * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < n) {
-        for (int s0 = sl; s0 < splits; s0 += 128 * 8) {
+        for (int s0 = sl; s0 < splits; s0 += SL * 8) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int sidx = s0 + 128 * u;
+                const int sidx = s0 + SL * u;
                 v[u] = sidx < splits ? *reinterpret_cast<const float4*>(slab + (size_t)sidx * stride + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -1327,7 +1343,7 @@ __global__ __launch_bounds__(1024) void reduce_slabs_cols_kernel(const float* __
     if (tid < 8 && col < n) {
         float4 t = red[0][tid];
 #pragma unroll
-        for (int w = 1; w < 16; ++w) { t.x += red[w][tid].x; t.y += red[w][tid].y; t.z += red[w][tid].z; t.w += red[w][tid].w; }
+        for (int w = 1; w < NWV; ++w) { t.x += red[w][tid].x; t.y += red[w][tid].y; t.z += red[w][tid].z; t.w += red[w][tid].w; }
         float* dst = col < n0 ? out0 + col : out1 + (col - n0);      // parameter blocks of the flat gradient are only 4-byte aligned
         dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;
     }
@@ -1335,13 +1351,14 @@ __global__ __launch_bounds__(1024) void reduce_slabs_cols_kernel(const float* __
 
 static bool reduce_cols_ok(const float* slab, const float* out0, const float* out1, int n0, int n, size_t stride) {
     (void)out0; (void)out1;
-    return n <= 2048 && n % 4 == 0 && n0 % 4 == 0 && stride % 4 == 0 && ((uintptr_t)slab) % 16 == 0;
+    return n % 4 == 0 && n0 % 4 == 0 && stride % 4 == 0 && ((uintptr_t)slab) % 16 == 0;
 }
 
 // out0[0..n0) += column sums of slab[:, 0..n0), out1[0..n1) += column sums of slab[:, n0..n0+n1)   (slab rows `stride` floats apart)
 void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s) {
     if (reduce_cols_ok(slab, out0, out1, n0, n0 + n1, stride)) {
-        hipLaunchKernelGGL(reduce_slabs_cols_kernel, dim3((n0 + n1 + 31) / 32), dim3(1024), 0, s, slab, out0, out1, n0, n0 + n1, splits, stride);
+        if (n0 + n1 <= 2048) hipLaunchKernelGGL(reduce_slabs_cols_kernel<128>, dim3((n0 + n1 + 31) / 32), dim3(1024), 0, s, slab, out0, out1, n0, n0 + n1, splits, stride);
+        else hipLaunchKernelGGL(reduce_slabs_cols_kernel<32>, dim3((n0 + n1 + 31) / 32), dim3(256), 0, s, slab, out0, out1, n0, n0 + n1, splits, stride);
         return;
     }
     launch_reduce_slabs(slab, out0, n0, splits, stride, s);
@@ -1350,12 +1367,13 @@ void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, i
 
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s) {
     if (reduce_cols_ok(slab, out, nullptr, n, n, stride)) {
-        hipLaunchKernelGGL(reduce_slabs_cols_kernel, dim3((n + 31) / 32), dim3(1024), 0, s, slab, out, (float*)nullptr, n, n, splits, stride);
+        if (n <= 2048) hipLaunchKernelGGL(reduce_slabs_cols_kernel<128>, dim3((n + 31) / 32), dim3(1024), 0, s, slab, out, (float*)nullptr, n, n, splits, stride);
+        else hipLaunchKernelGGL(reduce_slabs_cols_kernel<32>, dim3((n + 31) / 32), dim3(256), 0, s, slab, out, (float*)nullptr, n, n, splits, stride);
         return;
     }
     const int gx = (n + 1023) / 1024;
     int gy = 1;                                            // split groups: enough workgroups to fill the chip
-    while (gx * gy < 512 && gy * 16 <= splits) gy *= 2;
+    while (gx * gy < 256 && gy * 16 <= splits) gy *= 2;     // same-address atomics are expensive: 8-way 106 us, 4-way 83 us per wgrad (incl. GEMM)
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, gy), dim3(256), 0, s, slab, out, n, splits, stride);
 }
 
