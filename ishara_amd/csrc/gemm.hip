@@ -1397,6 +1397,8 @@ size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM) {
 
 int g_force_tn_regstage = 0;   // tests: force the register-transposing TN kernel
 
+int g_tn_phase = 0;            // 0: GEMM + slab sums; 1: GEMM kernel only; 2: slab sums only (the model profiles the two separately)
+
 static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s) {
     const int tiles = (Ka / 128) * (Nb / 128);
     int want = max(1, 512 / tiles);                       // two 64 KB-LDS workgroups per CU
@@ -1405,9 +1407,12 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
     const int rps = ((M + want - 1) / want + TR_ROWS - 1) / TR_ROWS * TR_ROWS;
     const int splits = (M + rps - 1) / rps;
     float* bias_slab = dbias ? slab + (size_t)splits * Ka * Nb : nullptr;
-    hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn);
-    launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
-    if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
+    if (g_tn_phase != 2)
+        hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn);
+    if (g_tn_phase != 1) {
+        launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
+        if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1420,10 +1425,13 @@ static int run_tn(int opA, int opB, const void* A, const void* B, float* out, fl
     const int tiles = ((Ka + 127) / 128) * ((Nb + 127) / 128);
     const int a_ok = (((size_t)Ka * sizeof(TA)) % 16 == 0) && (((uintptr_t)A) % 16 == 0);
     const int b_ok = (((size_t)Nb * sizeof(TB)) % 16 == 0) && (((uintptr_t)B) % 16 == 0);
-    hipLaunchKernelGGL((gemm_tn_kernel<TA, TB, TM>), dim3(tiles, splits), dim3(256), 0, s,
-                       (const TA*)A, (const TB*)B, slab, bias_slab, M, Ka, Nb, rps, a_ok, b_ok, opA, opB, oa, ob, g_dbg_tn);
-    launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
-    if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
+    if (g_tn_phase != 2)
+        hipLaunchKernelGGL((gemm_tn_kernel<TA, TB, TM>), dim3(tiles, splits), dim3(256), 0, s,
+                           (const TA*)A, (const TB*)B, slab, bias_slab, M, Ka, Nb, rps, a_ok, b_ok, opA, opB, oa, ob, g_dbg_tn);
+    if (g_tn_phase != 1) {
+        launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
+        if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -53,6 +53,7 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
                    const OpArgs& oa, const OpArgs& ob, hipStream_t s);
 
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
+extern int g_tn_phase;   // 0 GEMM + slab sums, 1 GEMM kernel only, 2 slab sums only
 const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb);
 
 // weight shadows: Wt[Np][Kp] (transposed) and Wn[Kp2][Np2] (as-is, padded) in dtM

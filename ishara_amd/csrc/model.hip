@@ -466,7 +466,12 @@ static int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA,
 }
 static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
+    // the GEMM kernel and the sums of its split-M slabs are profiled under separate keys (the kernel's key is its rocprof name)
+    g_tn_phase = 1;
     CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s));
+    g_tn_phase = 2;
+    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s));
+    g_tn_phase = 0;
     return 0;
 }
 
