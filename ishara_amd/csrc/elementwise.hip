@@ -31,27 +31,39 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     float ga[8], be[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ga[e] = act ? gamma[gl * 8 + e] : 0.f; be[e] = act ? beta[gl * 8 + e] : 0.f; }
-    for (int row = blockIdx.x * RPB + gr; row < M; row += gridDim.x * RPB) {
-        float v[8];
-        if (act) load8(x + (size_t)row * C + gl * 8, v);
-        else {
+    // four rows in flight per lane group
+    const int stride = gridDim.x * RPB;
+    for (int row0 = blockIdx.x * RPB + gr; row0 < M; row0 += 4 * stride) {
+        float v[4][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + u * stride;
+            if (act && row < M) load8(x + (size_t)row * C + gl * 8, v[u]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+            }
         }
-        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[e];
-        const float mu = group_sum<G>(s) / (float)C;
-        float q = 0.f;
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + u * stride;
+            float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = act ? v[e] - mu : 0.f; q += d * d; }
-        const float rs = rsqrtf(group_sum<G>(q) / (float)C + eps);
-        if (act) {
+            for (int e = 0; e < 8; ++e) s += v[u][e];
+            const float mu = group_sum<G>(s) / (float)C;
+            float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu) * rs * ga[e] + be[e];
-            store8(y + (size_t)row * C + gl * 8, v);
+            for (int e = 0; e < 8; ++e) { const float d = act ? v[u][e] - mu : 0.f; q += d * d; }
+            const float rs = rsqrtf(group_sum<G>(q) / (float)C + eps);
+            if (row < M) {
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[u][e] = (v[u][e] - mu) * rs * ga[e] + be[e];
+                    store8(y + (size_t)row * C + gl * 8, v[u]);
+                }
+                if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
+            }
         }
-        if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
 
@@ -60,7 +72,7 @@ int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float*
     if (C % 8 != 0 || C > 512) { ishara_set_error("layernorm: C=%d unsupported (need C%%8==0, C<=512)", C); return -1; }
     const int G = next_pow2(C / 8);
     const int rpb = 256 / G;
-    const int grid = min((M + rpb - 1) / rpb, 4096);
+    const int grid = max(1, min((M + 4 * rpb - 1) / (4 * rpb), 2048));
 #define LN_F(TT, GG) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, GG>), dim3(grid), dim3(256), 0, s, (const TT*)x, gamma, beta, eps, (TT*)y, mean, rstd, M, C)
 #define LN_FG(TT) switch (G) { case 1: LN_F(TT, 1); break; case 2: LN_F(TT, 2); break; case 4: LN_F(TT, 4); break; case 8: LN_F(TT, 8); break; \
                                case 16: LN_F(TT, 16); break; case 32: LN_F(TT, 32); break; default: LN_F(TT, 64); break; }
@@ -377,17 +389,21 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const T* __restrict__ x
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) dw_load_in(x, b, t0 - padl + j, Tn, C, Cin, ch, inop, win[j]);
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int LB = K <= 5 ? K : 4;           // input rows whose loads are in flight together (K = 11, 15: batches of 4)
     for (int tb = t0; tb < tend; tb += K) {
-        float nv[K][4], ng[K][4];                // the K new input rows of this group: all loads in flight together
 #pragma unroll
-        for (int u = 0; u < K; ++u) dw_raw(x, b, (tb + u < tend) ? tb + u - padl + K - 1 : -1, Tn, C, Cin, ch, inop, nv[u], ng[u]);
+      for (int u0 = 0; u0 < K; u0 += LB) {
+        float nv[LB][4], ng[LB][4];
 #pragma unroll
-        for (int u = 0; u < K; ++u) {            // output t = tb + u uses slots (u + j) % K ; the new input lands in slot (u + K - 1) % K
+        for (int uu = 0; uu < LB; ++uu) dw_raw(x, b, (u0 + uu < K && tb + u0 + uu < tend) ? tb + u0 + uu - padl + K - 1 : -1, Tn, C, Cin, ch, inop, nv[uu], ng[uu]);
+#pragma unroll
+        for (int uu = 0; uu < LB; ++uu) {        // output t = tb + u uses slots (u + j) % K ; the new input lands in slot (u + K - 1) % K
+            const int u = u0 + uu;
             const int t = tb + u;
-            if (t < tend) {
-                dw_xform(inop, nv[u], ng[u]);
+            if (u < K && t < tend) {
+                dw_xform(inop, nv[uu], ng[uu]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) win[(u + K - 1) % K][e] = nv[u][e];
+                for (int e = 0; e < 4; ++e) win[(u + K - 1) % K][e] = nv[uu][e];
                 float o[4] = {bv[0], bv[1], bv[2], bv[3]};
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
@@ -420,6 +436,7 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const T* __restrict__ x
                 }
             }
         }
+      }
     }
     if (ssum) {
         const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -595,7 +612,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_win_kernel(const T* __restri
     }
 }
 
-static bool dw_reg_ok(int C, int k) { return (k == 3 || k == 5) && C % 4 == 0   /* K = 11, 15 need > 250 VGPRs: LDS-tiled kernels */ && C / 4 <= 256 && 256 % (C / 4) == 0; }
+static bool dw_reg_ok(int C, int k) { return (k == 3 || k == 5) && C % 4 == 0   /* K = 11, 15: the register window (201 / 233 VGPRs) measured 94 / 103 us vs 82 / 86 us for the LDS-tiled kernel */ && C / 4 <= 256 && 256 % (C / 4) == 0; }
 int g_force_dw_lds = 0;    // tests: force the LDS-tiled kernels
 
 template <typename T>
