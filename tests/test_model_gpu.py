@@ -9,6 +9,7 @@ Tolerances (stated per SURVEY §8d / BASELINE.md):
              relative, per-tensor gradient relative L2 error <= 0.12.
 The oracle is evaluated in float64.  PARITY UNPINNED against TensorFlow itself (no TF here; the
 reference holds no golden vectors for this path — SURVEY §8c)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -175,3 +176,30 @@ def test_fit_surface():
     assert len(h.history["loss"]) == 3 and np.isfinite(h.history["loss"]).all() and np.isfinite(h.history["val_loss"]).all()
     assert h.history["loss"][-1] < h.history["loss"][0]      # 9 steps on 3 batches: the CTC loss goes down
     assert model.optimizer.iterations == 9
+
+
+def test_callback_eval_report(tmp_path):
+    """CallbackEval (c9:1-29): saves weights, prints Target / Prediction pairs from the HIP greedy decoder and
+    records the normalised-Levenshtein score (c18) of the batch."""
+    from ishara_amd.evaluation import CallbackEval, make_num_to_char
+    from ishara_amd.data import BatchAdapter
+    from oracle import ishara_oracle as O
+    kw = CFGS["tiny"]
+    ocfg = _oracle_cfg(kw, 0.0)
+    model = _build(kw, "bf16", 0.0)
+    x, y = O.synthetic_batch(ocfg, kw["B"], seed=5)
+    num_to_char = make_num_to_char({chr(ord("a") + i % 26) + str(i // 26): i for i in range(59)})
+    lines = []
+    wpath = str(tmp_path / "model.npz")
+    cb = CallbackEval([(x, y)], num_to_char, n_show=3, weights_path=wpath, printer=lines.append)
+    h = model.fit([(x, y)], epochs=1, callbacks=[cb], verbose=0)
+    assert os.path.exists(wpath)
+    assert sum(l.startswith("Target    : ") for l in lines) == 3 and sum(l.startswith("Prediction: ") for l in lines) == 3
+    assert lines[0] == "-" * 100 and ", len: " in [l for l in lines if l.startswith("Prediction")][0]
+    assert cb.last_score is not None and cb.last_score <= 1.0
+    assert "val_levenshtein" in h.history
+    # the reported predictions are exactly decode_batch of the eval-mode logits
+    logits = model(x, training=False)
+    want = ["".join(num_to_char.get(int(i), "") for i in idx) for idx in model.decode_batch(logits)]
+    got = [l[len("Prediction: "):].rsplit(", len: ", 1)[0] for l in lines if l.startswith("Prediction: ")]
+    assert got == want[:3]
