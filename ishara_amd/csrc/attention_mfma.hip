@@ -134,15 +134,15 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
             const uint32_t rkey = rng_row_key(drop.key, (uint32_t)(bh * Tn + qbase + 16 * t + c));
             float p[4][4];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], cs, mnc));
                     l_run[t] += pv;
-                    float pd = pv;
-                    if (drop.thr) pd = rng_keep(rkey, (uint32_t)(key0 + 16 * kt + 4 * g + r), drop.thr) ? pv * drop.scale : 0.f;
-                    p[kt][r] = pd;
+                    p[kt][r] = pv;
                 }
+                if (drop.thr) rng_apply<4>(rkey, (uint32_t)(key0 + 16 * kt + 4 * g), drop.thr, drop.scale, p[kt]);   // 4 consecutive keys: 2 hashes
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 w;
@@ -320,15 +320,18 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dq_mfma_kernel
                 const uint32_t rkey = rng_row_key(drop.key, (uint32_t)(bh * Tn + qbase + 16 * t + c));
                 float ds[4][4];
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt) {
+                    float dp[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[r] = dpa[kt][t][r];
+                    if (drop.thr) rng_apply<4>(rkey, (uint32_t)(key0 + 16 * kt + 4 * g), drop.thr, drop.scale, dp);     // 4 consecutive keys: 2 hashes
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = key0 + 16 * kt + 4 * g + r;
                         const float pv = (!partial || key < Tn) ? __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], cs, -lsl[t])) : 0.f;
-                        float dp = dpa[kt][t][r];
-                        if (drop.thr) dp = rng_keep(rkey, (uint32_t)key, drop.thr) ? dp * drop.scale : 0.f;
-                        ds[kt][r] = pv * (dp - dlt[t]) * scale;
+                        ds[kt][r] = pv * (dp[r] - dlt[t]) * scale;
                     }
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) dsb[t][ks] = pack8(ds[2 * ks], ds[2 * ks + 1]);
             }

@@ -100,18 +100,38 @@ __host__ __device__ __forceinline__ uint32_t rng_site_key(uint32_t seed, uint32_
 __host__ __device__ __forceinline__ uint32_t rng_row_key(uint32_t site_key, uint32_t row) {
     return lowbias32(site_key ^ (row * 0x85EBCA6Bu));
 }
-__host__ __device__ __forceinline__ bool rng_keep(uint32_t row_key, uint32_t col, uint32_t thr) {
-    return lowbias32(row_key ^ col) >= thr;
+// One hash serves a PAIR of columns (2k, 2k+1): 16 bits each, low half for the even column.  The hash (two quarter-rate
+// 32-bit multiplies) is 60 % of the VALU work of an attention score; kernels whose lanes own consecutive columns call
+// rng_pair once per pair.  keep iff the column's 16 bits >= thr16 = round(rate * 65536): P(keep) = 1 - thr16 / 65536.
+__host__ __device__ __forceinline__ uint32_t rng_pair(uint32_t row_key, uint32_t col) {
+    return lowbias32(row_key ^ (col >> 1));
 }
+__host__ __device__ __forceinline__ bool rng_keep(uint32_t row_key, uint32_t col, uint32_t thr) {
+    const uint32_t h = rng_pair(row_key, col);
+    return ((col & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr;
+}
+#if defined(__HIPCC__)
+// inverted dropout of N consecutive columns starting at an EVEN column: one hash per pair
+template <int N>
+__device__ __forceinline__ void rng_apply(uint32_t row_key, uint32_t col_even, uint32_t thr, float scale, float (&v)[N]) {
+    static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+        const uint32_t h = rng_pair(row_key, col_even + e);
+        v[e] = (h & 0xffffu) >= thr ? v[e] * scale : 0.f;
+        v[e + 1] = (h >> 16) >= thr ? v[e + 1] * scale : 0.f;
+    }
+}
+#endif
 static inline uint32_t rng_threshold(float rate) {
-    double t = (double)rate * 4294967296.0;
+    double t = (double)rate * 65536.0 + 0.5;
     if (t < 0) t = 0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
 }
 struct DropSpec {          // one dropout application
     uint32_t key;          // rng_site_key(seed, site)
-    uint32_t thr;          // keep iff hash >= thr ; thr==0 -> disabled
+    uint32_t thr;          // 16-bit threshold: keep iff the column's half of the pair hash >= thr ; thr==0 -> disabled
     float scale;           // 1/(1-rate)
 };
 static inline DropSpec make_drop(uint32_t seed, uint32_t site, float rate, bool training) {

@@ -1305,7 +1305,11 @@ __global__ __launch_bounds__(256) void map_rows_kernel(const T* __restrict__ x, 
                 for (int e = 0; e < 8; ++e) v[e] *= sc;
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = rng_keep(rk, (uint32_t)(chunk * 8 + e), drop.thr) ? v[e] * drop.scale : 0.f;
+                for (int e = 0; e < 8; e += 2) {
+                    const uint32_t h = rng_pair(rk, (uint32_t)(chunk * 8 + e));
+                    v[e] = (h & 0xffffu) >= drop.thr ? v[e] * drop.scale : 0.f;
+                    v[e + 1] = (h >> 16) >= drop.thr ? v[e + 1] * drop.scale : 0.f;
+                }
             }
             store8(y + off, v);
         }

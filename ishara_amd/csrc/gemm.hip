@@ -176,7 +176,11 @@ DEVI void epilogue_chunk(float (&v)[8], int m, int n, int nv, int N, const EpiAr
     if (ea.drop.thr) {
         const uint32_t rk = rng_row_key(ea.drop.key, (uint32_t)m);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = rng_keep(rk, (uint32_t)(n + e), ea.drop.thr) ? v[e] * ea.drop.scale : 0.f;
+        for (int e = 0; e < 8; e += 2) {       // n is a multiple of 8: one hash per column pair
+            const uint32_t h = rng_pair(rk, (uint32_t)(n + e));
+            v[e] = (h & 0xffffu) >= ea.drop.thr ? v[e] * ea.drop.scale : 0.f;
+            v[e + 1] = (h >> 16) >= ea.drop.thr ? v[e + 1] * ea.drop.scale : 0.f;
+        }
     }
     if (ea.rowscale) {
         const float s = ea.rowscale[m / ea.T];
@@ -283,7 +287,11 @@ struct EpiRows {
             if (ea.drop.thr) {
                 const uint32_t rk = rng_row_key(ea.drop.key, (uint32_t)m[q]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = rng_keep(rk, (uint32_t)(n + e), ea.drop.thr) ? v[e] * ea.drop.scale : 0.f;
+                for (int e = 0; e < 8; e += 2) {       // n is a multiple of 8: one hash per column pair
+            const uint32_t h = rng_pair(rk, (uint32_t)(n + e));
+            v[e] = (h & 0xffffu) >= ea.drop.thr ? v[e] * ea.drop.scale : 0.f;
+            v[e + 1] = (h >> 16) >= ea.drop.thr ? v[e + 1] * ea.drop.scale : 0.f;
+        }
             }
             if (ea.rowscale) {
 #pragma unroll

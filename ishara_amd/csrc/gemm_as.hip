@@ -266,8 +266,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
                     }
                 }
                 if (f_drop) {
-#pragma unroll
-                    for (int e = 0; e < GW; ++e) v[e] = rng_keep(rk[i], (uint32_t)(n + e), ea.drop.thr) ? v[e] * ea.drop.scale : 0.f;
+                    rng_apply<GW>(rk[i], (uint32_t)n, ea.drop.thr, ea.drop.scale, v);        // n is a multiple of GW
                 }
                 if (f_rowscale) {
 #pragma unroll

@@ -12,8 +12,9 @@ bit-identical masks for any (seed, site, row, col):
 
     key_site = lowbias32(seed ^ (site * 0x9E3779B9))
     key_row  = lowbias32(key_site ^ (row * 0x85EBCA6B))
-    r        = lowbias32(key_row ^ col)
-    keep     = r >= floor(rate * 2^32)
+    h        = lowbias32(key_row ^ (col >> 1))        one hash per PAIR of columns (2k, 2k+1)
+    r16      = h & 0xffff if col is even else h >> 16
+    keep     = r16 >= round(rate * 2^16)              (clamped to [0, 65535])
 
 Inverted dropout: kept elements are scaled by 1/(1-rate) (Keras semantics).
 """
@@ -40,8 +41,8 @@ def site_key(seed, site):
 
 
 def threshold(rate):
-    t = int(float(rate) * 4294967296.0)
-    return np.uint32(min(max(t, 0), 0xFFFFFFFF))
+    t = int(float(np.float32(rate)) * 65536.0 + 0.5)
+    return np.uint32(min(max(t, 0), 65535))
 
 
 def keep_mask(seed, site, rows, cols, rate):
@@ -51,8 +52,9 @@ def keep_mask(seed, site, rows, cols, rate):
         r = np.arange(rows, dtype=np.uint32) * np.uint32(0x85EBCA6B)
     key_row = lowbias32(ks ^ r)                       # [rows]
     c = np.arange(cols, dtype=np.uint32)
-    h = lowbias32(key_row[:, None] ^ c[None, :])      # [rows, cols]
-    return h >= threshold(rate)
+    h = lowbias32(key_row[:, None] ^ (c[None, :] >> np.uint32(1)))      # [rows, cols]: one hash per column pair
+    r16 = np.where((c[None, :] & np.uint32(1)) == 1, h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return r16 >= threshold(rate)
 
 
 def scaled_mask(seed, site, rows, cols, rate, dtype=np.float32):
