@@ -826,68 +826,58 @@ int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const flo
 // per-sample reductions over time:  S1[b,c] += sum_t dy ; S2[b,c] += sum_t dy * o,
 // o = other (optionally normalised (other-mean)*rstd).  grid = (B, time splits).
 // =====================================================================================
+// grid = (B, ceil(C / 128)): a workgroup owns 128 channels of one sample — 16 chunk lanes (8 channels, 16 bytes) x 16 row
+// lanes, four rows in flight per lane — and WRITES its sums (no atomics, no zero-fill launches).
 template <typename T>
 __global__ __launch_bounds__(256) void sample_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ other,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ S1, float* __restrict__ S2, int B, int Tn, int C) {
-    __shared__ float red[2][256][8];
-    const int tid = threadIdx.x;
-    const int nch = C >> 3;
-    const int CL = min(nch, 256), RL = 256 / CL;
-    const int cl = tid % CL, rl = tid / CL;
+    __shared__ float red[2][16][16][8];
+    const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
     const int b = blockIdx.x;
-    const int tper = (Tn + gridDim.y - 1) / gridDim.y;
-    const int tb = blockIdx.y * tper, te = min(Tn, tb + tper);
-    for (int cb = 0; cb < nch; cb += CL) {
-        const int chunk = cb + cl;
-        const bool act = chunk < nch && rl < RL;
-        float a[8], q[8], mu[8], rs[8];
+    const int chunk = blockIdx.y * 16 + cl;
+    const bool act = chunk * 8 < C;
+    float a[8], q[8], mu[8], rs[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; mu[e] = (act && mean) ? mean[chunk * 8 + e] : 0.f; rs[e] = (act && mean) ? rstd[chunk * 8 + e] : 1.f; }
-        if (act) {
-            // four rows (eight 16-byte loads with `other`) in flight per lane
-            for (int t0 = tb + rl; t0 < te; t0 += 4 * RL) {
-                float d[4][8], o[4][8];
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; mu[e] = (act && mean) ? mean[chunk * 8 + e] : 0.f; rs[e] = (act && mean) ? rstd[chunk * 8 + e] : 1.f; }
+    if (act) {
+        for (int t0 = rl; t0 < Tn; t0 += 64) {
+            float d[4][8], o[4][8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + u * RL;
-                    const size_t off = ((size_t)b * Tn + min(t, te - 1)) * C + chunk * 8;
-                    load8(dy + off, d[u]);
-                    if (other) load8(other + off, o[u]);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(t0 + 16 * u, Tn - 1);
+                const size_t off = ((size_t)b * Tn + t) * C + chunk * 8;
+                load8(dy + off, d[u]);
+                if (other) load8(other + off, o[u]);
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (t0 + u * RL < te) {
+            for (int u = 0; u < 4; ++u) {
+                if (t0 + 16 * u < Tn) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { a[e] += d[u][e]; if (other) q[e] += d[u][e] * ((o[u][e] - mu[e]) * rs[e]); }
-                    }
+                    for (int e = 0; e < 8; ++e) { a[e] += d[u][e]; if (other) q[e] += d[u][e] * ((o[u][e] - mu[e]) * rs[e]); }
                 }
             }
         }
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { red[0][tid][e] = a[e]; red[1][tid][e] = q[e]; }
-        __syncthreads();
-        if (rl == 0 && chunk < nch) {
+    for (int e = 0; e < 8; ++e) { red[0][rl][cl][e] = a[e]; red[1][rl][cl][e] = q[e]; }
+    __syncthreads();
+    if (tid < 128) {            // thread -> channel tid of the 128
+        const int c = blockIdx.y * 128 + tid;
+        if (c < C) {
+            float sa = 0.f, sq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float sa = 0.f, sq = 0.f;
-                for (int r = 0; r < RL; ++r) { sa += red[0][r * CL + cl][e]; sq += red[1][r * CL + cl][e]; }
-                atomicAdd(S1 + (size_t)b * C + chunk * 8 + e, sa);
-                if (S2) atomicAdd(S2 + (size_t)b * C + chunk * 8 + e, sq);
-            }
+            for (int r = 0; r < 16; ++r) { sa += red[0][r][tid >> 3][tid & 7]; sq += red[1][r][tid >> 3][tid & 7]; }
+            S1[(size_t)b * C + c] = sa;
+            if (S2) S2[(size_t)b * C + c] = sq;
         }
-        __syncthreads();
     }
 }
 
 int launch_sample_reduce(int dt, const void* dy, const void* other, const float* mean, const float* rstd,
                          float* S1, float* S2, int B, int T, int C, hipStream_t s) {
     if (C % 8 != 0) { ishara_set_error("sample_reduce: C%%8 != 0"); return -1; }
-    (void)hipMemsetAsync(S1, 0, (size_t)B * C * sizeof(float), s);
-    if (S2) (void)hipMemsetAsync(S2, 0, (size_t)B * C * sizeof(float), s);
-    int ts = max(1, min(8, 1024 / max(B, 1)));
-    ts = min(ts, max(1, T / 16));
-    dim3 grid(B, ts);
+    dim3 grid(B, (C + 127) / 128);
     if (dt == DT_BF16) hipLaunchKernelGGL(sample_reduce_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)other, mean, rstd, S1, S2, B, T, C);
     else hipLaunchKernelGGL(sample_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)other, mean, rstd, S1, S2, B, T, C);
     return LAUNCH_OK();

@@ -1155,6 +1155,8 @@ DEVI bf16x8 tr_frag(const char* tile, int lb, int s, int lane) {
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                          float* __restrict__ out, float* __restrict__ dbias,
                                                          int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, int dbg) {
+    // slab layout: [split][Ka*Nb weight partial | Nb bias partial] so that ONE reduction launch sums both
+    const size_t sstride = (size_t)Ka * Nb + Nb;
     __shared__ __attribute__((aligned(16))) char smem[TR_NSTAGE * TR_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1257,7 +1259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         stage[(16 * ii + 4 * (lane >> 4) + r) * SLD + 16 * j + (lane & 15)] = acc[2 * p + ii][j][r];
-            float* orow = out + (size_t)split * Ka * Nb + (size_t)(k0 + wr * 64 + 32 * p + (lane >> 4)) * Nb + n0 + wc * 64 + (lane & 15) * 4;
+            float* orow = out + (size_t)split * sstride + (size_t)(k0 + wr * 64 + 32 * p + (lane >> 4)) * Nb + n0 + wc * 64 + (lane & 15) * 4;
 #pragma unroll
             for (int it = 0; it < 8; ++it)       // one instruction = 4 rows x 256 contiguous bytes
                 *reinterpret_cast<float4*>(orow + (size_t)(4 * it) * Nb) = *reinterpret_cast<const float4*>(stage + ((lane >> 4) + 4 * it) * SLD + (lane & 15) * 4);
@@ -1269,7 +1271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
             float t = csum[j];
             t += __shfl_xor(t, 16, 64);
             t += __shfl_xor(t, 32, 64);
-            if (lane < 16) dbias[(size_t)split * Nb + n0 + wc * 64 + 16 * j + lane] = t;
+            if (lane < 16) dbias[(size_t)split * sstride + n0 + wc * 64 + 16 * j + lane] = t;
         }
     }
 }
@@ -1414,13 +1416,11 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
     if (want > maxs) want = maxs;
     const int rps = ((M + want - 1) / want + TR_ROWS - 1) / TR_ROWS * TR_ROWS;
     const int splits = (M + rps - 1) / rps;
-    float* bias_slab = dbias ? slab + (size_t)splits * Ka * Nb : nullptr;
+    float* bias_slab = dbias ? slab + (size_t)Ka * Nb : nullptr;        // bias partials sit right behind each split's weight partial
     if (g_tn_phase != 2)
         hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn);
-    if (g_tn_phase != 1) {
-        launch_reduce_slabs(slab, out, Ka * Nb, splits, (size_t)Ka * Nb, s);
-        if (dbias) launch_reduce_slabs(bias_slab, dbias, Nb, splits, (size_t)Nb, s);
-    }
+    if (g_tn_phase != 1)
+        launch_reduce_slabs2(slab, out, Ka * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1484,6 +1484,39 @@ __global__ void make_shadow_kernel(const float* __restrict__ W, int K, int N, TM
             if (k < K && n < N) Wt[(size_t)n * ldt + k] = from_f<TM>(tile[tx][r]);
         }
     }
+}
+
+// all weight shadows of the model in ONE launch: block -> (weight, 32x32 tile) through a descriptor table in device memory
+template <typename TM>
+__global__ void make_shadow_batched_kernel(const ShadowDesc* __restrict__ tab, int ntab) {
+    __shared__ float tile[32][33];
+    int wi = 0;
+    while (wi + 1 < ntab && (int)blockIdx.x >= tab[wi + 1].tile0) ++wi;
+    const ShadowDesc d = tab[wi];
+    const int lt = blockIdx.x - d.tile0;
+    const int k0 = (lt / d.tiles_n) * 32, n0 = (lt % d.tiles_n) * 32;
+    TM* Wt = reinterpret_cast<TM*>(d.Wt);
+    TM* Wn = reinterpret_cast<TM*>(d.Wn);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        float v = 0.f;
+        if (k < d.K && n < d.N) { v = d.W[(size_t)k * d.N + n]; if (Wn) Wn[(size_t)k * d.ldn + n] = from_f<TM>(v); }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (Wt) {
+        for (int r = ty; r < 32; r += 8) {
+            const int n = n0 + r, k = k0 + tx;
+            if (k < d.K && n < d.N) Wt[(size_t)n * d.ldt + k] = from_f<TM>(tile[tx][r]);
+        }
+    }
+}
+int launch_make_shadow_batched(int dtM, const ShadowDesc* tab, int ntab, int total_tiles, hipStream_t s) {
+    if (ntab <= 0 || total_tiles <= 0) return 0;
+    if (dtM == DT_BF16) hipLaunchKernelGGL(make_shadow_batched_kernel<bf16>, dim3(total_tiles), dim3(256), 0, s, tab, ntab);
+    else hipLaunchKernelGGL(make_shadow_batched_kernel<float>, dim3(total_tiles), dim3(256), 0, s, tab, ntab);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt, void* Wn, int ldn, hipStream_t s) {

@@ -58,6 +58,8 @@ const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int
 
 // weight shadows: Wt[Np][Kp] (transposed) and Wn[Kp2][Np2] (as-is, padded) in dtM
 int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt, void* Wn, int ldn, hipStream_t s);
+struct ShadowDesc { const float* W; void* Wt; void* Wn; int K, N, ldt, ldn, tile0, tiles_n; };   // tile0: first 32x32 tile (block) of this weight
+int launch_make_shadow_batched(int dtM, const ShadowDesc* tab, int ntab, int total_tiles, hipStream_t s);
 
 // ---- normalisation / conv / small ops (elementwise.hip) ---------------------------
 int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float* beta, float eps,
