@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void greedy_decode_kernel(const float* __restr
 }
 
 int launch_greedy_decode(const float* logits, int B, int T, int C, int blank, int* out_idx, int* out_len, hipStream_t s) {
-    (void)hipMemsetAsync(out_idx, 0xFF, (size_t)B * T * sizeof(int), s);   // -1 fill
+    (void)launch_fill_u32(out_idx, (size_t)B * T, 0xFFFFFFFFu, s);   // -1 fill (a kernel, not a memset node: see model.hip)
     hipLaunchKernelGGL(greedy_decode_kernel, dim3(B), dim3(256), 2 * T * sizeof(int), s, logits, T, C, blank, out_idx, out_len);
     return LAUNCH_OK();
 }

@@ -135,6 +135,7 @@ size_t ctc_workspace_floats(int B, int T, int L);
 // logits [B,T,C] f32; labels [B,L] int64 (padded with blank); nll [B]; dlogits = grad_scale * d nll_b / d logits
 int launch_ctc(const float* logits, const int64_t* labels, int B, int T, int C, int L, int blank,
                float* nll, float* dlogits, float grad_scale, float* ws, hipStream_t s);
+int launch_fill_u32(void* p, size_t n_words, uint32_t v, hipStream_t s);   // model.hip
 int launch_mean(const float* v, float* out, int n, float scale, hipStream_t s);
 int launch_greedy_decode(const float* logits, int B, int T, int C, int blank, int* out_idx, int* out_len, hipStream_t s);
 

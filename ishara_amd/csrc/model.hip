@@ -40,6 +40,17 @@ extern "C" const char* ishara_last_error(void) { return g_err; }
 static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------ small kernels
+// fills inside forward / backward use a kernel rather than hipMemsetAsync: under hipGraph capture the memset NODES of this
+// ROCm build intermittently corrupted neighbouring workspace (tests/test_tflite_gpu.py, graph mode)
+__global__ void fill_u32_kernel(uint32_t* p, size_t n, uint32_t v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int launch_fill_u32(void* p, size_t n_words, uint32_t v, hipStream_t s) {
+    if (n_words == 0) return 0;
+    const int grid = (int)((n_words + 255) / 256 < 1024 ? (n_words + 255) / 256 : 1024);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(grid), dim3(256), 0, s, (uint32_t*)p, n_words, v);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 __global__ void droppath_kernel(float* rs, int B, DropSpec d) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) rs[b] = (d.thr == 0u || rng_keep(rng_row_key(d.key, (uint32_t)b), 0u, d.thr)) ? d.scale : 0.f;
@@ -142,7 +153,10 @@ struct ishara_model {
     // temps
     Buf gA, gB, t1, t2, t3, S1, S2, E, Fc, Ecol, dse, dgapT, slab, ctcws, dlogits, nllb, delta;
     size_t shadow_begin = 0, shadow_end = 0;
-    ShadowDesc* shadow_tab = nullptr;      // device table of the batched shadow build (owned; freed in ishara_destroy)
+    size_t shadow_tab_off = 0;             // device descriptor table of the batched shadow build, inside the workspace (no
+                                           // hipMalloc/hipFree of our own: a hipFree from a garbage-collected model would break a
+                                           // stream capture in progress elsewhere in the process)
+    std::vector<ShadowDesc> shadow_tab_host;
     int shadow_ntab = 0, shadow_tiles = 0;
     bool shadow_ready = false;
     size_t ws_need = 0;
@@ -316,6 +330,7 @@ static void plan_workspace(ishara_model* m) {
     later.push_back(&m->topW); later.push_back(&m->clsW);
     for (DenseW* w : later) plan_shadow(m, *w);
     m->shadow_end = m->cur;
+    m->shadow_tab_off = m->alloc(m->denses.size() * sizeof(ShadowDesc)).off;
     // ---- stem
     m->pe = m->f32((size_t)T * d);
     m->stem_h0 = m->act(d); m->stem_out = m->act(d);
@@ -420,7 +435,7 @@ extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     *out = m;
     return 0;
 }
-extern "C" void ishara_destroy(ishara_model* m) { if (m && m->shadow_tab) (void)hipFree(m->shadow_tab); delete m; }
+extern "C" void ishara_destroy(ishara_model* m) { delete m; }
 extern "C" int64_t ishara_param_total(const ishara_model* m) { return m->n_total; }
 extern "C" int64_t ishara_param_trainable(const ishara_model* m) { return m->n_train; }
 extern "C" int32_t ishara_param_entries(const ishara_model* m) { return (int32_t)m->entries.size(); }
@@ -465,12 +480,11 @@ extern "C" int ishara_sync_weights(ishara_model* m, ishara_stream st) {
         }
         m->shadow_tiles = tile0;
         m->shadow_ntab = (int)tab.size();
-        if (m->shadow_tab) (void)hipFree(m->shadow_tab);
-        HIP_CHECK_RET(hipMalloc(&m->shadow_tab, tab.size() * sizeof(ShadowDesc)));
-        HIP_CHECK_RET(hipMemcpy(m->shadow_tab, tab.data(), tab.size() * sizeof(ShadowDesc), hipMemcpyHostToDevice));
+        m->shadow_tab_host = tab;
+        HIP_CHECK_RET(hipMemcpyAsync(m->ws + m->shadow_tab_off, m->shadow_tab_host.data(), tab.size() * sizeof(ShadowDesc), hipMemcpyHostToDevice, s));
         m->shadow_ready = true;
     }
-    CK(launch_make_shadow_batched(m->dt, m->shadow_tab, m->shadow_ntab, m->shadow_tiles, s));
+    CK(launch_make_shadow_batched(m->dt, reinterpret_cast<const ShadowDesc*>(m->ws + m->shadow_tab_off), m->shadow_ntab, m->shadow_tiles, s));
     return 0;
 }
 
@@ -505,8 +519,8 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     const int d = m->d, c = 2 * d, B = r.B, T = m->T, dt = m->dt;
     OpArgs no; EpiArgs e1;
     CK(gemm_fwd(m, cb.W1, x, dt, m->W(cb.z1), dt, r.M, OP_NONE, no, e1));
-    HIP_CHECK_RET(hipMemsetAsync(m->W(cb.ssum), 0, (size_t)B * c * 4, m->s));
-    HIP_CHECK_RET(hipMemsetAsync(m->W(cb.ssq), 0, (size_t)B * c * 4, m->s));
+    CK(launch_fill_u32(m->W(cb.ssum), (size_t)B * c, 0u, m->s));
+    CK(launch_fill_u32(m->W(cb.ssq), (size_t)B * c, 0u, m->s));
     CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), B, T, c, cb.k, cb.k - 1, m->s));
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(cb.ssum), m->Wf(cb.ssq), B, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
                           m->P(cb.bn.mm), m->P(cb.bn.mv), r.training, m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.bsh), c, m->s));
@@ -567,8 +581,8 @@ static int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* 
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
     CK(gemm_fwd(m, c.Wp1, x, dt, m->W(c.g), dt, r.M, OP_NONE, no, e0));
-    HIP_CHECK_RET(hipMemsetAsync(m->W(c.ssum), 0, (size_t)B * d * 4, m->s));
-    HIP_CHECK_RET(hipMemsetAsync(m->W(c.ssq), 0, (size_t)B * d * 4, m->s));
+    CK(launch_fill_u32(m->W(c.ssum), (size_t)B * d, 0u, m->s));
+    CK(launch_fill_u32(m->W(c.ssq), (size_t)B * d, 0u, m->s));
     CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), B, T, d, c.k, (c.k - 1) / 2, m->s));
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), 1e-3f, 0.99f,
                           m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s));
