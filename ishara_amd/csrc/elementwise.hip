@@ -14,9 +14,18 @@ static inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p;
 // LayerNorm.  A row is owned by a group of G lanes (G = pow2 >= C/8, <= 64), each lane
 // holding one 8-channel chunk in registers (C <= 512) -> exact two-pass statistics.
 // =====================================================================================
+// sum over aligned groups of G lanes.  Within a 16-lane DPP row the butterfly runs on the VALU (quad_perm / row_half_mirror /
+// row_mirror: no LDS round trip); only the steps across rows (G = 32, 64) use ds_bpermute.
+template <int CTRL> DEVI float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 template <int G> DEVI float group_sum(float v) {
+    if constexpr (G >= 2) v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]: lane ^ 1
+    if constexpr (G >= 4) v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]: lane ^ 2
+    if constexpr (G >= 8) v = dpp_add<0x141>(v);         // row_half_mirror: lane -> 7 - lane within 8 (sums the two quads)
+    if constexpr (G >= 16) v = dpp_add<0x140>(v);        // row_mirror: lane -> 15 - lane within 16
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 16; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                     for (int e = 0; e < 8; ++e) v[u][e] = (v[u][e] - mu) * rs * ga[e] + be[e];
                     store8(y + (size_t)row * C + gl * 8, v[u]);
                 }
-                if (gl == 0) { mean[row] = mu; rstd[row] = rs; }
+                if (gl == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
             }
         }
     }
@@ -72,7 +81,7 @@ int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float*
     if (C % 8 != 0 || C > 512) { ishara_set_error("layernorm: C=%d unsupported (need C%%8==0, C<=512)", C); return -1; }
     const int G = next_pow2(C / 8);
     const int rpb = 256 / G;
-    const int grid = max(1, min((M + 4 * rpb - 1) / (4 * rpb), 2048));
+    const int grid = max(1, min((M + 4 * rpb - 1) / (4 * rpb), 8192));     // one 4-row batch per lane group at M = 98304 (3072 workgroups)
 #define LN_F(TT, GG) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, GG>), dim3(grid), dim3(256), 0, s, (const TT*)x, gamma, beta, eps, (TT*)y, mean, rstd, M, C)
 #define LN_FG(TT) switch (G) { case 1: LN_F(TT, 1); break; case 2: LN_F(TT, 2); break; case 4: LN_F(TT, 4); break; case 8: LN_F(TT, 8); break; \
                                case 16: LN_F(TT, 16); break; case 32: LN_F(TT, 32); break; default: LN_F(TT, 64); break; }
