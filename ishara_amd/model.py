@@ -212,6 +212,15 @@ class Model:
         with np.load(path if path.endswith(".npz") else path + ".npz") as z:
             self.set_weights({k: z[k] for k in z.files})
 
+    def save_keras_weights(self, path: str):
+        """Ordered list of `keras_model.get_weights()` as arr_0.. (keras_interchange.py)."""
+        from . import keras_interchange as K
+        K.save_keras_npz(path, self.get_weights(), [(n, tuple(s)) for n, s, _, _ in self.entries])
+
+    def load_keras_weights(self, path: str):
+        from . import keras_interchange as K
+        self.set_weights(K.load_keras_npz(path, [(n, tuple(s)) for n, s, _, _ in self.entries]))
+
     def count_params(self): return self.n_total
 
     def summary(self, print_fn=print):

@@ -39,10 +39,10 @@ def _oracle_cfg(kw, dropout):
                     conformer_attn_dropout=0.1 if dropout > 0 else 0.0, **k)
 
 
-def _build(kw, dtype, dropout):
+def _build(kw, dtype, dropout, seed=3):
     k = {a: b for a, b in kw.items() if a != "B"}
     return get_model(dropout_rate=dropout, head_dropout=0.4 if dropout > 0 else 0.0,
-                     conformer_attn_dropout=0.1 if dropout > 0 else 0.0, dtype=dtype, max_batch=kw["B"], seed=3, **k)
+                     conformer_attn_dropout=0.1 if dropout > 0 else 0.0, dtype=dtype, max_batch=kw["B"], seed=seed, **k)
 
 
 def _perturb(model):
@@ -203,3 +203,21 @@ def test_callback_eval_report(tmp_path):
     want = ["".join(num_to_char.get(int(i), "") for i in idx) for idx in model.decode_batch(logits)]
     got = [l[len("Prediction: "):].rsplit(", len: ", 1)[0] for l in lines if l.startswith("Prediction: ")]
     assert got == want[:3]
+
+
+def test_keras_interchange_matches_model(tmp_path):
+    """Model.entries lists the same (name, shape) pairs, in the same layer order, as the oracle's param_specs (which the
+    CPU interchange tests use); the Keras-ordered export round-trips through a second model and gives identical logits."""
+    from oracle import ishara_oracle as O
+    kw = CFGS["tiny"]
+    ocfg = _oracle_cfg(kw, 0.0)
+    model = _build(kw, "f32", 0.0)
+    assert [(n, tuple(s)) for n, s, _, _ in model.entries] == [(n, tuple(s)) for n, s, _, _ in O.param_specs(ocfg)]
+    p = str(tmp_path / "keras.npz")
+    model.save_keras_weights(p)
+    other = _build(kw, "f32", 0.0, seed=99)
+    x, _ = O.synthetic_batch(ocfg, kw["B"], seed=1)
+    a = model(x, training=False).cpu().numpy()
+    assert np.abs(other(x, training=False).cpu().numpy() - a).max() > 1e-3
+    other.load_keras_weights(p)
+    assert np.array_equal(other(x, training=False).cpu().numpy(), a)
