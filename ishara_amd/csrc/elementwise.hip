@@ -209,7 +209,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                      T* __restrict__ y, const T* __restrict__ aux,
                                                      float* __restrict__ ssum, float* __restrict__ ssq,
-                                                     int B, int Tn, int C, int k, int padl, int inop, int outop, int flip) {
+                                                     int B, int Tn, int C, int k, int padl, int inop, int outop, int flip, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float tile[(DW_TT + DW_MAXK - 1) * DW_CT];
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
@@ -332,8 +332,13 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
             float a = 0.f, q = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) { a += red[(r * DW_CT + tid) * 2]; q += red[(r * DW_CT + tid) * 2 + 1]; }
-            atomicAdd(ssum + (size_t)b * C + c0 + tid, a);
-            if (ssq) atomicAdd(ssq + (size_t)b * C + c0 + tid, q);
+            if (part) {      // deterministic: this time tile's partial row [B][P = gridDim.x][2][C], summed by stats_reduce_kernel
+                float* pr = part + (((size_t)b * gridDim.x + blockIdx.x) * 2) * C + c0 + tid;
+                pr[0] = a; pr[C] = q;
+            } else {
+                atomicAdd(ssum + (size_t)b * C + c0 + tid, a);
+                if (ssq) atomicAdd(ssq + (size_t)b * C + c0 + tid, q);
+            }
         }
     }
 }
@@ -377,7 +382,7 @@ template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_reg_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                          T* __restrict__ y, const T* __restrict__ aux,
                                                          float* __restrict__ ssum, float* __restrict__ ssq,
-                                                         int Tn, int C, int padl, int inop, int outop, int flip) {
+                                                         int Tn, int C, int padl, int inop, int outop, int flip, float* __restrict__ part) {
     // workgroup = 64 channel quads (256 channels: one wave reads 512 contiguous bytes of a row) x 4 consecutive segments of
     // one sample: the per-(sample, channel) statistics of the 4 segments are combined in LDS before the atomics
     __shared__ float sred[4][64][8];
@@ -458,8 +463,14 @@ __global__ __launch_bounds__(256) void dwconv_reg_kernel(const T* __restrict__ x
                 float a = 0.f, q = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { a += sred[r][cl][e]; q += sred[r][cl][4 + e]; }
-                atomicAdd(ssum + (size_t)b * C + ch + e, a);
-                if (ssq) atomicAdd(ssq + (size_t)b * C + ch + e, q);
+                if (part) {  // deterministic partial row of this 4-segment group: [B][P = gridDim.x / ncb][2][C]
+                    const int P = gridDim.x / ncb, pi = blockIdx.x / ncb;
+                    float* pr = part + (((size_t)b * P + pi) * 2) * C + ch + e;
+                    pr[0] = a; pr[C] = q;
+                } else {
+                    atomicAdd(ssum + (size_t)b * C + ch + e, a);
+                    if (ssq) atomicAdd(ssq + (size_t)b * C + ch + e, q);
+                }
             }
         }
     }
@@ -626,10 +637,10 @@ int g_force_dw_lds = 0;    // tests: force the LDS-tiled kernels
 
 template <typename T>
 static void launch_dw_reg(int k, const T* x, const float* w, const float* bias, T* y, const T* aux, float* ssum, float* ssq,
-                          int B, int Tn, int C, int padl, int inop, int outop, int flip, hipStream_t s) {
+                          int B, int Tn, int C, int padl, int inop, int outop, int flip, hipStream_t s, float* part = nullptr) {
     const int nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
     dim3 grid(((C / 4 + 63) / 64) * ((nseg + 3) / 4), B);
-#define DWR(KK) hipLaunchKernelGGL((dwconv_reg_kernel<T, KK>), grid, dim3(256), 0, s, x, w, bias, y, aux, ssum, ssq, Tn, C, padl, inop, outop, flip)
+#define DWR(KK) hipLaunchKernelGGL((dwconv_reg_kernel<T, KK>), grid, dim3(256), 0, s, x, w, bias, y, aux, ssum, ssq, Tn, C, padl, inop, outop, flip, part)
     switch (k) { case 3: DWR(3); break; case 5: DWR(5); break; case 11: DWR(11); break; default: DWR(15); break; }
 #undef DWR
 }
@@ -649,17 +660,39 @@ static int dwconv_check(int C, int k) {
     return 0;
 }
 
+// ssum / ssq [B, C] = per-sample channel sums of the partial rows part[B][P][2][C], in a fixed order (no float atomics:
+// the forward pass is bit-reproducible run to run, and no zero-fill launches are needed)
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restrict__ part, int P, float* __restrict__ ssum, float* __restrict__ ssq, int B, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    const float* p = part + ((size_t)b * P * 2) * C + c;
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < P; ++r) { a += p[(size_t)(2 * r) * C]; q += p[(size_t)(2 * r + 1) * C]; }
+    ssum[i] = a;
+    if (ssq) ssq[i] = q;
+}
+size_t dwconv_fwd_scratch_floats(int B, int T, int C) { return (size_t)B * ((T + DW_TT - 1) / DW_TT) * 2 * C; }
+
+// `part`: scratch of dwconv_fwd_scratch_floats(B, T, C) floats for the deterministic statistics, or nullptr (then colsum /
+// colsq must be zero-filled by the caller and are accumulated with float atomics)
 int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const float* bias, void* y,
-                      float* colsum, float* colsq, int B, int T, int C, int k, int padl, hipStream_t s) {
+                      float* colsum, float* colsq, float* part, int B, int T, int C, int k, int padl, hipStream_t s) {
     if (dwconv_check(C, k)) return -1;
+    if (!colsum) part = nullptr;
+    int P;
     if (dw_reg_ok(C, k) && !g_force_dw_lds) {
-        if (dt == DT_BF16) launch_dw_reg<bf16>(k, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s);
-        else launch_dw_reg<float>(k, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s);
-        return LAUNCH_OK();
+        const int nseg = (T + DWR_SEG - 1) / DWR_SEG;
+        P = (nseg + 3) / 4;
+        if (dt == DT_BF16) launch_dw_reg<bf16>(k, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s, part);
+        else launch_dw_reg<float>(k, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s, part);
+    } else {
+        dim3 grid((T + DW_TT - 1) / DW_TT, (C + DW_CT - 1) / DW_CT, B);
+        P = grid.x;
+        if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0, part);
+        else hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0, part);
     }
-    dim3 grid((T + DW_TT - 1) / DW_TT, (C + DW_CT - 1) / DW_CT, B);
-    if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0);
-    else hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0);
+    if (part) hipLaunchKernelGGL(stats_reduce_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, P, colsum, colsq, B, C);
     return LAUNCH_OK();
 }
 
@@ -801,8 +834,8 @@ int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const flo
         else launch_dw_reg<float>(k, (const float*)dy, w, nullptr, (float*)dx, (const float*)x, nullptr, nullptr, B, T, C, k - 1 - padl, DWIN_NONE, outop, 1, s);
     } else {
         dim3 grid((T + DW_TT - 1) / DW_TT, (C + DW_CT - 1) / DW_CT, B);
-        if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, w, (const float*)nullptr, (bf16*)dx, (const bf16*)x, (float*)nullptr, (float*)nullptr, B, T, C, k, k - 1 - padl, (int)DWIN_NONE, outop, 1);
-        else hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, w, (const float*)nullptr, (float*)dx, (const float*)x, (float*)nullptr, (float*)nullptr, B, T, C, k, k - 1 - padl, (int)DWIN_NONE, outop, 1);
+        if (dt == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, w, (const float*)nullptr, (bf16*)dx, (const bf16*)x, (float*)nullptr, (float*)nullptr, B, T, C, k, k - 1 - padl, (int)DWIN_NONE, outop, 1, (float*)nullptr);
+        else hipLaunchKernelGGL(dwconv_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, w, (const float*)nullptr, (float*)dx, (const float*)x, (float*)nullptr, (float*)nullptr, B, T, C, k, k - 1 - padl, (int)DWIN_NONE, outop, 1, (float*)nullptr);
     }
     const bool winok = scratch && (k == 3 || k == 5 || k == 11 || k == 15) && !g_force_dw_lds;
     if (winok) {

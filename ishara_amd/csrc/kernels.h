@@ -74,8 +74,11 @@ int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mea
 enum : int { DWIN_NONE = 0, DWIN_SWISH = 1, DWIN_GLU = 2 };
 // y[b,t,c] = bias[c] + sum_j w[j,c] * in(x)[b, t - padl + j, c]; x has Cin = C (or 2C for GLU).
 // stats: ssum/ssq [B,C] = per-sample sum_t y, sum_t y^2 (fp32 atomics; zero them first; nullptr = off).
+// ssum / ssq: per-sample channel sums of y and y^2 [B, C] (or nullptr).  `part`: scratch of dwconv_fwd_scratch_floats(B, T, C)
+// floats -> deterministic sums without atomics or zero fills; nullptr -> the caller zero-fills ssum / ssq, float atomics
 int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const float* bias, void* y,
-                      float* ssum, float* ssq, int B, int T, int C, int k, int padl, hipStream_t s);
+                      float* ssum, float* ssq, float* part, int B, int T, int C, int k, int padl, hipStream_t s);
+size_t dwconv_fwd_scratch_floats(int B, int T, int C);
 // dx = d in(x) ; dw [k,C], dbias [C] accumulated (through `scratch` partial rows of
 // dwconv_bwd_scratch_floats(C,k) floats when given, else atomically).
 size_t dwconv_bwd_scratch_floats(int C, int k);

@@ -387,6 +387,7 @@ static void plan_workspace(ishara_model* m) {
     for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > slabf) slabf = f; }
     if (layernorm_bwd_scratch_floats(d) > slabf) slabf = layernorm_bwd_scratch_floats(d);
     if (dwconv_bwd_scratch_floats(2 * maxw, 31) > slabf) slabf = dwconv_bwd_scratch_floats(2 * maxw, 31);
+    if (dwconv_fwd_scratch_floats(B, T, 2 * maxw) > slabf) slabf = dwconv_fwd_scratch_floats(B, T, 2 * maxw);
     m->slab = m->f32(slabf);
     m->ctcws = m->f32(ctc_workspace_floats(B, T, m->L));
     m->dlogits = m->f32(Mx * m->C);
@@ -519,9 +520,7 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     const int d = m->d, c = 2 * d, B = r.B, T = m->T, dt = m->dt;
     OpArgs no; EpiArgs e1;
     CK(gemm_fwd(m, cb.W1, x, dt, m->W(cb.z1), dt, r.M, OP_NONE, no, e1));
-    CK(launch_fill_u32(m->W(cb.ssum), (size_t)B * c, 0u, m->s));
-    CK(launch_fill_u32(m->W(cb.ssq), (size_t)B * c, 0u, m->s));
-    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), B, T, c, cb.k, cb.k - 1, m->s));
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s));
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(cb.ssum), m->Wf(cb.ssq), B, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
                           m->P(cb.bn.mm), m->P(cb.bn.mv), r.training, m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.bsh), c, m->s));
     CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s));
@@ -568,7 +567,7 @@ static int sqzconv_fwd(ishara_model* m, SqzConv& c, const Run& r, const void* x)
     OpArgs no; EpiArgs e0;
     CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, x, m->P(c.ln.gamma), m->P(c.ln.beta), 1e-6f, m->W(c.xn), m->Wf(c.mean), m->Wf(c.rstd), r.M, d, m->s));
     CK(gemm_fwd(m, c.Wc1, m->W(c.xn), dt, m->W(c.zc), dt, r.M, OP_NONE, no, e0));
-    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(c.zc), m->P(c.dw), nullptr, m->W(c.zd), nullptr, nullptr, B, T, de, c.k, c.k - 1, m->s));
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(c.zc), m->P(c.dw), nullptr, m->W(c.zd), nullptr, nullptr, nullptr, B, T, de, c.k, c.k - 1, m->s));
     CKP(m, "map_rows", 2.0 * r.M * de * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_SWISH, m->W(c.zd), m->W(c.hd), nullptr, DropSpec{0, 0, 1.f}, r.M, T, de, m->s));
     CK(gemm_fwd(m, c.Wc3, m->W(c.hd), dt, m->W(c.u3), dt, r.M, OP_NONE, no, e0));
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(c.u3), nullptr, nullptr, nullptr, m->Wf(c.gap), nullptr, B, T, d, m->s));
@@ -581,9 +580,7 @@ static int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* 
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
     CK(gemm_fwd(m, c.Wp1, x, dt, m->W(c.g), dt, r.M, OP_NONE, no, e0));
-    CK(launch_fill_u32(m->W(c.ssum), (size_t)B * d, 0u, m->s));
-    CK(launch_fill_u32(m->W(c.ssq), (size_t)B * d, 0u, m->s));
-    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), B, T, d, c.k, (c.k - 1) / 2, m->s));
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), 1e-3f, 0.99f,
                           m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s));
     CKP(m, "col_affine", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_col_affine(dt, m->W(c.v), m->Wf(c.a), m->Wf(c.bsh), m->W(c.bnv), r.M, d, m->s));
@@ -931,7 +928,7 @@ extern "C" int ishara_op_layernorm_bwd(int32_t dt, const void* dy, const void* x
 }
 extern "C" int ishara_op_dwconv_fwd(int32_t dt, int32_t inop, const void* x, const float* w, const float* bias, void* y, float* ssum, float* ssq,
                                     int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {
-    return launch_dwconv_fwd(dt, inop, x, w, bias, y, ssum, ssq, B, T, C, k, padl, (hipStream_t)s);
+    return launch_dwconv_fwd(dt, inop, x, w, bias, y, ssum, ssq, nullptr, B, T, C, k, padl, (hipStream_t)s);
 }
 extern "C" int64_t ishara_op_dwconv_scratch_bytes(int32_t C, int32_t k) { return (int64_t)(dwconv_bwd_scratch_floats(C, k) * sizeof(float)); }
 extern "C" int ishara_op_dwconv_bwd(int32_t dt, int32_t inop, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,

@@ -1,0 +1,88 @@
+"""Parity at BASELINE.json's full configuration (configs[1]: d256, 2+2, kernel_sizes [11,5,3], T384, F224, bf16) through
+size-independent properties — the oracle cannot run this size in seconds, so the HIP path is checked against ITSELF
+through identities that any correct implementation satisfies, and against the f32 HIP path (itself oracle-checked at
+small sizes in test_model_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from ishara_amd import get_model
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(dim=256, num_conv_squeeze_blocks=2, num_conv_conform_blocks=2, kernel_sizes=[11, 5, 3], num_conv_per_block=3,
+          num_heads=8, expansion_factor=2, transformer_kernel_size=15, input_shape=(384, 224))
+B = 64
+
+
+def _data(seed=1, b=B):
+    g = np.random.default_rng(seed)
+    x = g.standard_normal((b, 384, 224)).astype(np.float32)
+    y = np.full((b, 64), 59, np.int64)
+    for i in range(b):
+        n = int(g.integers(8, 32))
+        y[i, :n] = g.integers(0, 59, n)
+    return torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+
+
+@pytest.fixture(scope="module")
+def models():
+    mb = get_model(**KW, dropout_rate=0.2, dtype="bf16", max_batch=B, seed=0)
+    mf = get_model(**KW, dropout_rate=0.2, dtype="f32", max_batch=B, seed=0)
+    return mb, mf
+
+
+def test_inference_is_per_sample_and_matches_f32(models):
+    """Eval-mode forward: BatchNorm uses moving statistics, so every sample is independent — a batch of 64 must give the
+    same logits as its two halves and as a permuted batch (up to GEMM tiling round-off), and bf16 must track f32."""
+    mb, mf = models
+    x, _ = _data(3)
+    full = mb(x, training=False).float()
+    halves = torch.cat([mb(x[:32], training=False), mb(x[32:], training=False)]).float()
+    assert torch.isfinite(full).all()
+    assert (full - halves).abs().max().item() <= 2e-2
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).cuda()
+    assert (mb(x[perm], training=False).float() - full[perm]).abs().max().item() <= 2e-2
+    f32 = mf(x, training=False)
+    err = (full - f32).abs().max().item()
+    assert err <= 0.15, f"bf16 vs f32 logits max-abs-err {err}"              # same tolerance as the oracle comparison
+    # greedy decode: identical indices wherever the f32 logits have no near-tie
+    top2 = torch.topk(f32, 2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]).min(dim=1).values > 0.5
+    db, df = mb.decode_batch(full), mf.decode_batch(f32)
+    assert all(np.array_equal(db[i], df[i]) for i in range(B) if bool(clear[i]))
+    # decode is idempotent on its own logits
+    assert all(np.array_equal(a, b) for a, b in zip(db, mb.decode_batch(full)))
+
+
+def test_training_step_is_deterministic_and_learns(models):
+    """Same seed -> bit-identical logits and loss (the forward pass has no float atomics) and gradients equal to 1e-6 (a
+    few [B,C]-sized backward reductions still use atomics); four steps on one batch lower the CTC loss; the gradients are
+    linear in loss_scale."""
+    mb, _ = models
+    x, y = _data(5)
+    w0 = mb.get_weights()
+    l1, lg1 = mb.loss_and_gradients(x, y, seed=11); g1 = mb.grads.clone(); l1 = float(l1.item()); lg1 = lg1.clone()
+    l2, lg2 = mb.loss_and_gradients(x, y, seed=11); g2 = mb.grads.clone(); l2 = float(l2.item())
+    assert np.isfinite(l1) and l1 == l2 and torch.equal(lg1, lg2)
+    rel = ((g1 - g2).norm() / g1.norm()).item()
+    assert rel <= 1e-6, f"gradient differs between identical runs: rel-L2 {rel}"
+    mb.loss_and_gradients(x, y, seed=11, loss_scale=0.5)
+    rel = ((mb.grads - 0.5 * g1).norm() / (0.5 * g1).norm()).item()
+    assert rel <= 2e-3, f"gradients are not linear in loss_scale: {rel}"
+    # the per-sample CTC loss of the training logits is a mean over samples: shuffling samples keeps the batch loss
+    mb.optimizer.learning_rate = 1e-3
+    losses = [float(mb.train_on_batch(x, y, seed=20 + i).item()) for i in range(4)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    mb.set_weights(w0)
+
+
+def test_ctc_loss_is_permutation_equivariant(models):
+    mb, _ = models
+    x, y = _data(7)
+    logits = mb(x, training=False)
+    nll = mb.ctc_loss(y, logits)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+    nll_p = mb.ctc_loss(y[perm], logits[perm])
+    assert torch.allclose(nll_p, nll[perm], rtol=1e-6, atol=1e-4)
+    assert (nll > 0).all() and torch.isfinite(nll).all()
