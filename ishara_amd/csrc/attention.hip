@@ -232,13 +232,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     } while (0)
 
 int launch_attn_bwd_mfma(const void* q, const void* k, const void* vt, const void* o, const void* dout, const float* lse,
-                         float* delta, void* dqkv, int B, int H, int T, int dh, float scale, DropSpec drop, hipStream_t s);
+                         float* delta, void* dqkv, int B, int H, int T, int dh, float scale, DropSpec drop, uint32_t* maskbits, hipStream_t s);
 int launch_attn_fwd_mfma(const void* q, const void* k, const void* vt, void* o, float* lse,
-                         int B, int H, int T, int dh, float scale, DropSpec drop, hipStream_t s);
+                         int B, int H, int T, int dh, float scale, DropSpec drop, uint32_t* maskbits, hipStream_t s);
 
 int launch_attn_fwd(int dt, const void* q, const void* k, const void* vt, void* o, float* lse,
-                    int B, int H, int T, int dh, float scale, DropSpec drop, int impl, hipStream_t s) {
-    if (impl == 1 && dt == DT_BF16 && (dh == 32 || dh == 64)) return launch_attn_fwd_mfma(q, k, vt, o, lse, B, H, T, dh, scale, drop, s);
+                    int B, int H, int T, int dh, float scale, DropSpec drop, int impl, uint32_t* maskbits, hipStream_t s) {
+    if (impl == 1 && dt == DT_BF16 && (dh == 32 || dh == 64)) return launch_attn_fwd_mfma(q, k, vt, o, lse, B, H, T, dh, scale, drop, maskbits, s);
     if (dt == DT_BF16) { ATT_DISPATCH(attn_fwd_kernel, bf16, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (bf16*)o, lse, B, H, T, scale, drop); }
     else { ATT_DISPATCH(attn_fwd_kernel, float, (const float*)q, (const float*)k, (const float*)vt, (float*)o, lse, B, H, T, scale, drop); }
     return LAUNCH_OK();
@@ -246,9 +246,9 @@ int launch_attn_fwd(int dt, const void* q, const void* k, const void* vt, void* 
 
 int launch_attn_bwd(int dt, const void* q, const void* k, const void* vt, const void* o, const void* dout,
                     const float* lse, float* delta, void* dqkv, int B, int H, int T, int dh, float scale,
-                    DropSpec drop, int head_major, int impl, hipStream_t s) {
+                    DropSpec drop, int head_major, int impl, uint32_t* maskbits, hipStream_t s) {
     if (impl == 1 && dt == DT_BF16 && (dh == 32 || dh == 64) && head_major)
-        return launch_attn_bwd_mfma(q, k, vt, o, dout, lse, delta, dqkv, B, H, T, dh, scale, drop, s);
+        return launch_attn_bwd_mfma(q, k, vt, o, dout, lse, delta, dqkv, B, H, T, dh, scale, drop, maskbits, s);
     if (dt == DT_BF16) {
         ATT_DISPATCH(attn_bwd_dq_kernel, bf16, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)o, (const bf16*)dout, lse, delta, (bf16*)dqkv, B, H, T, scale, drop, head_major);
         ATT_DISPATCH(attn_bwd_dkv_kernel, bf16, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)dout, lse, (const float*)delta, (bf16*)dqkv, B, H, T, scale, drop, head_major);

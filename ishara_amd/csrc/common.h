@@ -112,6 +112,11 @@ __host__ __device__ __forceinline__ bool rng_keep(uint32_t row_key, uint32_t col
     return ((col & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr;
 }
 #if defined(__HIPCC__)
+// keep flags (bit e) of the 4 consecutive columns starting at a multiple of 4: two hashes
+__device__ __forceinline__ uint32_t rng_bits4(uint32_t row_key, uint32_t col4, uint32_t thr) {
+    const uint32_t h0 = rng_pair(row_key, col4), h1 = rng_pair(row_key, col4 + 2);
+    return ((h0 & 0xffffu) >= thr ? 1u : 0u) | ((h0 >> 16) >= thr ? 2u : 0u) | ((h1 & 0xffffu) >= thr ? 4u : 0u) | ((h1 >> 16) >= thr ? 8u : 0u);
+}
 // inverted dropout of N consecutive columns starting at an EVEN column: one hash per pair
 template <int N>
 __device__ __forceinline__ void rng_apply(uint32_t row_key, uint32_t col_even, uint32_t thr, float scale, float (&v)[N]) {

@@ -126,12 +126,15 @@ int launch_se_bwd(const float* dse, const float* gap, float invT, const float* W
 
 // ---- attention (attention.hip) -----------------------------------------------------
 // q,k [B,H,T,dh], vt [B,H,dh,T]; o [B*T, H*dh]; lse [B,H,T]
+// maskbits: attn_mask_words(B, H, T) dwords where the MFMA forward kernel stores the dropout keep flags for the backward
+// kernels (nullptr: the backward kernels hash again; the lane-split kernels always hash)
+size_t attn_mask_words(int B, int H, int T);
 int launch_attn_fwd(int dt, const void* q, const void* k, const void* vt, void* o, float* lse,
-                    int B, int H, int T, int dh, float scale, DropSpec drop, int impl, hipStream_t s);
+                    int B, int H, int T, int dh, float scale, DropSpec drop, int impl, uint32_t* maskbits, hipStream_t s);
 // dqkv [B*T, 3*H*dh] packed like the qkv projection output (head_major flag as in EpiArgs)
 int launch_attn_bwd(int dt, const void* q, const void* k, const void* vt, const void* o, const void* dout,
                     const float* lse, float* delta, void* dqkv, int B, int H, int T, int dh, float scale,
-                    DropSpec drop, int head_major, int impl, hipStream_t s);
+                    DropSpec drop, int head_major, int impl, uint32_t* maskbits, hipStream_t s);
 
 // ---- CTC / decode (ctc.hip) ----------------------------------------------------------
 size_t ctc_workspace_floats(int B, int T, int L);

@@ -102,7 +102,7 @@ struct FFN {
 };
 struct MHSA {
     Norm ln; float eps; DenseW Wqkv, Wp; float rate = 0.f; uint32_t site_attn = 0, site_out = 0; bool has_out_drop = false;
-    Buf xn, mean, rstd, q, k, vt, o, lse, out;
+    Buf xn, mean, rstd, q, k, vt, o, lse, out, maskw;
 };
 struct SqzConv {
     Norm ln; DenseW Wc1, Wc3; int dw = -1, seW1 = -1, seb1 = -1, seW2 = -1, seb2 = -1; int k = 0, R = 0;
@@ -352,6 +352,7 @@ static void plan_workspace(ishara_model* m) {
         a.xn = m->act(d); a.mean = m->f32(Mx); a.rstd = m->f32(Mx);
         a.q = m->act(d); a.k = m->act(d); a.vt = m->act(d); a.o = m->act(d);
         a.lse = m->f32((size_t)B * m->H * T); a.out = m->act(d);
+        a.maskw = m->f32(attn_mask_words(B, m->H, T));        // dropout keep bits of the attention probabilities (fwd -> bwd)
     };
     for (auto& sb : m->sqz) {
         plan_ffn_act(sb.ffn1); plan_mhsa_act(sb.mha);
@@ -555,7 +556,7 @@ static int mhsa_fwd(ishara_model* m, MHSA& a, const Run& r, const void* x) {
     CK(gemm_fwd(m, a.Wqkv, m->W(a.xn), dt, nullptr, dt, r.M, OP_NONE, no, eq));
     const float scale = 1.0f / sqrtf((float)m->d);     // self.scale = dim ** -0.5 (c5:95)
     CKP(m, "attn_fwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 4.0 * r.B * m->H * (double)m->T * m->T * m->dh, launch_attn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->Wf(a.lse), r.B, m->H, m->T, m->dh, scale,
-                       dspec(r, a.site_attn, a.rate), m->cfg.attn_impl, m->s));
+                       dspec(r, a.site_attn, a.rate), m->cfg.attn_impl, reinterpret_cast<uint32_t*>(m->W(a.maskw)), m->s));
     EpiArgs ep; ep.resid = x;
     if (a.has_out_drop) ep.drop = dspec(r, a.site_out, m->cfg.dropout_rate);
     CK(gemm_fwd(m, a.Wp, m->W(a.o), dt, m->W(a.out), dt, r.M, OP_NONE, no, ep));
@@ -691,7 +692,7 @@ static int mhsa_bwd(ishara_model* m, MHSA& a, const Run& r, const void* x, const
     CK(gemm_wgrad(m, a.Wp, m->W(a.o), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
     const float scale = 1.0f / sqrtf((float)m->d);
     CKP(m, "attn_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 10.0 * r.B * m->H * (double)m->T * m->T * m->dh, launch_attn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta), m->W(m->t2),
-                       r.B, m->H, m->T, m->dh, scale, dspec(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, m->s));
+                       r.B, m->H, m->T, m->dh, scale, dspec(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, reinterpret_cast<uint32_t*>(m->W(a.maskw)), m->s));
     CK(gemm_dgrad(m, a.Wqkv, m->W(m->t2), dt, m->W(m->t1), r.M, OP_NONE, no, e0));            // dxn
     CK(gemm_wgrad(m, a.Wqkv, m->W(a.xn), dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
     CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), m->Wf(m->slab), r.M, m->d, m->s));
@@ -938,29 +939,30 @@ extern "C" int ishara_op_dwconv_bwd(int32_t dt, int32_t inop, const void* dy, co
 // scratch layout: q | k | vt | lse | delta
 extern "C" int64_t ishara_op_attn_scratch_bytes(int32_t B, int32_t H, int32_t T, int32_t dh) {
     const size_t n = (size_t)B * H * T * dh;
-    return (int64_t)(3 * rup(n * 4, 256) + 2 * rup((size_t)B * H * T * 4, 256));
+    return (int64_t)(3 * rup(n * 4, 256) + 2 * rup((size_t)B * H * T * 4, 256) + rup(attn_mask_words(B, H, T) * 4, 256));
 }
-static void attn_scratch(char* sc, int dt, int B, int H, int T, int dh, void*& q, void*& k, void*& vt, float*& lse, float*& delta) {
+static void attn_scratch(char* sc, int dt, int B, int H, int T, int dh, void*& q, void*& k, void*& vt, float*& lse, float*& delta, uint32_t*& maskw) {
     const size_t n = (size_t)B * H * T * dh;
     const size_t seg = rup(n * 4, 256);
     (void)dt;
     q = sc; k = sc + seg; vt = sc + 2 * seg;
     lse = (float*)(sc + 3 * seg);
     delta = (float*)(sc + 3 * seg + rup((size_t)B * H * T * 4, 256));
+    maskw = (uint32_t*)(sc + 3 * seg + 2 * rup((size_t)B * H * T * 4, 256));
 }
 extern "C" int ishara_op_attn_fwd(int32_t dt, const void* qkv, void* o, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
                                   uint32_t seed, uint32_t site, float rate, int32_t impl, void* scratch, ishara_stream st) {
     hipStream_t s = (hipStream_t)st;
-    void *q, *k, *vt; float *lse, *delta;
-    attn_scratch((char*)scratch, dt, B, H, T, dh, q, k, vt, lse, delta);
+    void *q, *k, *vt; float *lse, *delta; uint32_t* maskw;
+    attn_scratch((char*)scratch, dt, B, H, T, dh, q, k, vt, lse, delta, maskw);
     if (dt == DT_BF16) hipLaunchKernelGGL(qkv_split_kernel<bf16>, dim3(1024), dim3(256), 0, s, (const bf16*)qkv, (bf16*)q, (bf16*)k, (bf16*)vt, B, H, T, dh);
     else hipLaunchKernelGGL(qkv_split_kernel<float>, dim3(1024), dim3(256), 0, s, (const float*)qkv, (float*)q, (float*)k, (float*)vt, B, H, T, dh);
-    return launch_attn_fwd(dt, q, k, vt, o, lse, B, H, T, dh, scale, make_drop(seed, site, rate, true), impl, s);
+    return launch_attn_fwd(dt, q, k, vt, o, lse, B, H, T, dh, scale, make_drop(seed, site, rate, true), impl, maskw, s);
 }
 extern "C" int ishara_op_attn_bwd(int32_t dt, const void* o, const void* dout, void* dqkv, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
                                   uint32_t seed, uint32_t site, float rate, int32_t impl, void* scratch, ishara_stream st) {
     hipStream_t s = (hipStream_t)st;
-    void *q, *k, *vt; float *lse, *delta;
-    attn_scratch((char*)scratch, dt, B, H, T, dh, q, k, vt, lse, delta);
-    return launch_attn_bwd(dt, q, k, vt, o, dout, lse, delta, dqkv, B, H, T, dh, scale, make_drop(seed, site, rate, true), 1, impl, s);
+    void *q, *k, *vt; float *lse, *delta; uint32_t* maskw;
+    attn_scratch((char*)scratch, dt, B, H, T, dh, q, k, vt, lse, delta, maskw);
+    return launch_attn_bwd(dt, q, k, vt, o, dout, lse, delta, dqkv, B, H, T, dh, scale, make_drop(seed, site, rate, true), 1, impl, maskw, s);
 }
