@@ -1152,6 +1152,7 @@ DEVI bf16x8 tr_frag(const char* tile, int lb, int s, int lane) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int DBG>      // DBG = 1: the ablation bits of tools/gemm_ablate.py are honoured (kept out of the production loop)
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                          float* __restrict__ out, float* __restrict__ dbias,
                                                          int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, int dbg) {
@@ -1188,18 +1189,44 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
     // fragments already in registers while the transposing LDS reads of stage mc+1 are in flight, and stages mc+2 .. mc+4
     // are in flight from L2/HBM (the slot of stage mc is free as soon as every wave has passed this iteration's barrier,
     // because its fragments were read during iteration mc-1).
+    // DMA source pointers of this lane for the NEXT stage to issue (advanced by 32 rows per issue: no 64-bit address
+    // arithmetic in the loop); stages are always issued in order 0, 1, 2, ...
+    const bf16* pa[2];
+    const bf16* pb[2];
+    {
+        const int r = lane >> 4, sp = lane & 15;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pc = wid + 4 * u, row = 4 * pc + r;
+            const int col = (((sp >> 1) ^ tr_f(row)) << 4) + ((sp & 1) << 3);
+            pa[u] = A + (size_t)(m_beg + row) * Ka + k0 + col;
+            pb[u] = B + (size_t)(m_beg + row) * Nb + n0 + col;
+        }
+    }
+    const size_t stepA = (size_t)TR_ROWS * Ka, stepB = (size_t)TR_ROWS * Nb;
     auto issue_stage = [&](int st) {
-        if (st < nmc && !(dbg & 4)) tr_issue(A, B, Ka, Nb, k0, n0, m_beg + st * TR_ROWS, smem + (st % TR_NSTAGE) * TR_STAGE, wid, lane);
+        if (st < nmc && !(DBG != 0 && (dbg & 4) != 0)) {
+            char* stage = smem + (st & (TR_NSTAGE - 1)) * TR_STAGE;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pc = wid + 4 * u;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[u],
+                                                 (__attribute__((address_space(3))) void*)(stage + pc * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[u],
+                                                 (__attribute__((address_space(3))) void*)(stage + 8192 + pc * 1024), 16, 0, 0);
+                pa[u] += stepA; pb[u] += stepB;
+            }
+        }
     };
     auto read_frags = [&](int st, bf16x8 (&a)[4], bf16x8 (&b)[4]) {
-        const char* sa = smem + (st % TR_NSTAGE) * TR_STAGE;
+        const char* sa = smem + (st & (TR_NSTAGE - 1)) * TR_STAGE;
         const char* sb = sa + 8192;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = (dbg & 2) ? bf16x8{} : tr_frag(sa, wr * 4 + i, 0, lane);
+        for (int i = 0; i < 4; ++i) a[i] = (DBG != 0 && (dbg & 2) != 0) ? bf16x8{} : tr_frag(sa, wr * 4 + i, 0, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = (dbg & 2) ? bf16x8{} : tr_frag(sb, wc * 4 + j, 0, lane);
+        for (int j = 0; j < 4; ++j) b[j] = (DBG != 0 && (dbg & 2) != 0) ? bf16x8{} : tr_frag(sb, wc * 4 + j, 0, lane);
     };
-    const int nmc_run = (dbg & 16) ? 0 : nmc;
+    const int nmc_run = (DBG != 0 && (dbg & 16) != 0) ? 0 : nmc;
     bf16x8 a_cur[4], b_cur[4], a_nxt[4], b_nxt[4];
 #pragma unroll
     for (int st = 0; st < TR_NSTAGE; ++st) issue_stage(st);
@@ -1229,7 +1256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
                 csum[j] += t;
             }
         }
-        if (!(dbg & 1)) {
+        if (!(DBG != 0 && (dbg & 1) != 0)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1246,7 +1273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
     // ---- write this split's 128x128 partial to its fp32 slab: each wave transposes its 64x64 accumulator block through
     // a private LDS stage (two 32-row passes) so that every store instruction writes 4 rows x 256 contiguous bytes
     __syncthreads();                       // the ring is free
-    if (dbg & 8) { if (acc[0][0][0] == 123.f) out[0] = acc[1][1][1]; return; }
+    if (DBG != 0 && (dbg & 8) != 0) { if (acc[0][0][0] == 123.f) out[0] = acc[1][1][1]; return; }
     {
         constexpr int SLD = 68;
         float* stage = reinterpret_cast<float*>(smem) + wid * (32 * SLD);
@@ -1418,7 +1445,10 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
     const int splits = (M + rps - 1) / rps;
     float* bias_slab = dbias ? slab + (size_t)Ka * Nb : nullptr;        // bias partials sit right behind each split's weight partial
     if (g_tn_phase != 2)
-        hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn);
+    {
+        if (g_dbg_tn) hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn);
+        else hipLaunchKernelGGL(gemm_tn_tr_kernel<0>, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0);
+    }
     if (g_tn_phase != 1)
         launch_reduce_slabs2(slab, out, Ka * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s);
     return hipGetLastError() == hipSuccess ? 0 : -2;

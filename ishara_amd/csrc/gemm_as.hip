@@ -64,7 +64,7 @@ template <int MASK, int F> DEVI bool as_on(bool runtime) {
 
 // One pass of a workgroup over all N columns for the rows [m_base, m_base + 64*RT): wave w owns rows m_base + 16*RT*w ..,
 // RT row tiles of 16.  KT = K / 32 (8 or 16); MASK: epilogue features.
-template <typename TC, int KT, int MASK, int RT>
+template <typename TC, int KT, int MASK, int RT, int DBG>
 DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, const EpiArgs& ea,
                   char* smem, const float* bias_s, int m_base) {
     constexpr int RB = KT * 64;                    // bytes of one staged weight row (full K)
@@ -80,6 +80,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
     constexpr bool COUNTED = (MASK & (AS_RESID | AS_DACT | AS_ADDTAB | AS_QKV)) == 0;   // epilogue = a fixed number of stores, no loads
     constexpr int OPS = SPS * ((MASK & AS_PREOUT) ? 2 : 1);
 
+    const int dbg = DBG ? ea.dbg : 0;          // ablation bits of tools/gemm_ablate.py, compiled out of the production kernels
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
@@ -112,7 +113,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
     };
 #pragma unroll
     for (int st = 0; st < R - 1; ++st)
-        if (st < nsteps && !(ea.dbg & 8)) issue(st * STAGE);       // dbg: ablation bits of tools/gemm_ablate.py (1 no epilogue, 2 no MFMA, 4 no LDS reads, 8 no DMA)
+        if (st < nsteps && !(dbg & 8)) issue(st * STAGE);       // dbg: ablation bits of tools/gemm_ablate.py (1 no epilogue, 2 no MFMA, 4 no LDS reads, 8 no DMA)
 
     // A fragments: lane (c, g) holds row 16i + c, k = 32kt + 8g .. +7
     bf16x8 a[RT][KT];
@@ -182,7 +183,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 #pragma unroll
                 for (int q = 0; q < NG; ++q) au[i][q] = *reinterpret_cast<const as_u32x4*>(aux + eoff[i] + n0 + 4 * GW * q);
         }
-        if (s + R - 1 < nsteps && !(ea.dbg & 8)) issue(slot == 0 ? (R - 1) * STAGE : slot - STAGE);
+        if (s + R - 1 < nsteps && !(dbg & 8)) issue(slot == 0 ? (R - 1) * STAGE : slot - STAGE);
         // ---- MFMA: acc[j][i] = sum_k Bt[row(j), k] * A[16i + .., k]
         f32x4 acc[2][RT];
 #pragma unroll
@@ -190,7 +191,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* st = smem + slot;
-        if (!(ea.dbg & 6)) {
+        if (!(dbg & 6)) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -200,7 +201,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
                     for (int i = 0; i < RT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i][kt], acc[j][i], 0, 0, 0);
                 }
             }
-        } else if (!(ea.dbg & 4)) {       // LDS reads only
+        } else if (!(dbg & 4)) {       // LDS reads only
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -208,7 +209,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
                     const f32x4 b = *reinterpret_cast<const f32x4*>(st + ((kt & 1) ? off_o : off_e) + (kt >> 1) * 128 + j * JSTRIDE);
                     acc[j][0] += b;
                 }
-        } else if (!(ea.dbg & 2)) {       // MFMA only
+        } else if (!(dbg & 2)) {       // MFMA only
             const bf16x8 b = a[0][0];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
@@ -220,7 +221,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[0][i][0] = (float)a[i][0][0] + (float)a[i][KT - 1][7];
         }
-        if (ea.dbg & 1) { if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][RT - 1][2]); slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE; continue; }
+        if (dbg & 1) { if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][RT - 1][2]); slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE; continue; }
         // ---- epilogue from the accumulators: lane owns row 16i + c and, per group q, columns n0 + 4*GW*q + GW*g .. +GW-1
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -313,7 +314,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 // K = 256: 128-row workgroups, 3 per CU (768 at M = 98304 = one round of the chip).  K = 512: the A fragments take 128
 // VGPRs, so only 2 workgroups fit per CU; 192-row workgroups (512 at M = 98304, again exactly one round) run as a
 // 128-row pass followed by a 64-row pass.
-template <typename TC, int KT, int MASK>
+template <typename TC, int KT, int MASK, int DBG = 0>
 __global__ __launch_bounds__(256, KT <= 8 ? 3 : 2) void gemm_nt_as_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C,
                                                                          int M, int N, int ldb, EpiArgs ea) {
     constexpr int R = KT <= 8 ? 3 : 2;
@@ -323,13 +324,13 @@ __global__ __launch_bounds__(256, KT <= 8 ? 3 : 2) void gemm_nt_as_kernel(const 
     // bias -> LDS (visible after the first barrier of the step loop)
     for (int n = threadIdx.x; n < N; n += 256) bias_s[n] = ea.bias ? ea.bias[n] : 0.f;
     if constexpr (KT <= 8) {
-        as_pass<TC, KT, MASK, 2>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
+        as_pass<TC, KT, MASK, 2, DBG>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
     } else {
         const int m_base = blockIdx.x * 192;
-        as_pass<TC, KT, MASK, 2>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base);
+        as_pass<TC, KT, MASK, 2, DBG>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base);
         if (m_base + 128 < M) {
             __builtin_amdgcn_s_barrier();          // every wave is done reading the ring before the second pass refills it
-            as_pass<TC, KT, MASK, 1>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base + 128);
+            as_pass<TC, KT, MASK, 1, DBG>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base + 128);
         }
     }
 }
@@ -358,7 +359,10 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     if constexpr (is_bf16_t<TC>::value) {
         // the feature combinations the encoder's forward / backward passes use (model.hip), compiled without the others
         switch (mask) {
-            case 0: AS_LAUNCH(0); break;
+            case 0:
+                if (ea.dbg) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, 0, 1>), grid, block, 0, s, (const bf16*)A, (const bf16*)Bt, (TC*)C, M, N, ldb, ea);
+                else AS_LAUNCH(0);
+                break;
             case AS_RESID: AS_LAUNCH(AS_RESID); break;                                           // W2 / Wb / Wp eval, dgrad + skip gradient
             case AS_RESID | AS_ROWSCALE: AS_LAUNCH(AS_RESID | AS_ROWSCALE); break;               // conv block W2 with drop-path
             case AS_RESID | AS_DROP: AS_LAUNCH(AS_RESID | AS_DROP); break;                       // Wb / Wp with output dropout
