@@ -1568,6 +1568,6 @@ const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A
 }
 const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb) {
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && opA == OP_NONE && opB == OP_NONE && M % 64 == 0 && Ka % 128 == 0 && Nb % 128 == 0 &&
-        M >= 256 && !g_force_tn_regstage) return "gemm_tn_tr_kernel";
+        M >= 256 && !g_force_tn_regstage) return "gemm_tn_tr_kernel<0>";
     return dtM == DT_F32 ? "gemm_tn_kernel<f32,f32,f32>" : (dtA == DT_F32 ? "gemm_tn_kernel<f32,bf16,bf16>" : (dtB == DT_F32 ? "gemm_tn_kernel<bf16,f32,bf16>" : "gemm_tn_kernel<bf16,bf16,bf16>"));
 }

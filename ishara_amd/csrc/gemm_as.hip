@@ -398,7 +398,7 @@ const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea) {
     auto it = names.find(id);
     if (it == names.end()) {
         char buf[96];
-        snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, inst);
+        snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d,0>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, inst);
         it = names.emplace(id, buf).first;
     }
     return it->second.c_str();
