@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dq_mfma_kernel
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = key0 + 16 * kt + 4 * g + r;
-                        const float pv = (!partial || key < Tn) ? __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], cs, -lsl[t])) : 0.f;
+                        const bool inb = (!partial) | (key < Tn);                // branchless: exp2(-inf) = 0 for the keys past the end
+                        const float xq = fmaf(sacc[kt][t][r], cs, -lsl[t]);
+                        const float pv = __builtin_amdgcn_exp2f(inb ? xq : -INFINITY);
                         ds[kt][r] = pv * (dp[r] - dlt[t]) * scale;
                     }
                 }
@@ -524,7 +526,9 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dkv_mfma_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ql = 32 * ks + 16 * hq + 4 * g + r;
-                        const float pv = (!partial || q0 + ql < Tn) ? __builtin_amdgcn_exp2f(fmaf(sacc[hq][r], cs, -Lc[ql])) : 0.f;
+                        const bool inb = (!partial) | (q0 + ql < Tn);            // branchless: exp2(-inf) = 0 for the queries past the end
+                        const float xq = fmaf(sacc[hq][r], cs, -Lc[ql]);          // unconditional LDS read + fma: no exec-mask branch per score
+                        const float pv = __builtin_amdgcn_exp2f(inb ? xq : -INFINITY);
                         float dp = dpa[hq][r], pdv = pv;
                         if constexpr (DM != 0) {
                             const bool keep = DM == 2 ? ((mw[t][r] >> (16 * hq + 4 * (((kbase + 16 * t) % AF_KC) >> 4) + (c & 3))) & 1u) != 0u
