@@ -45,7 +45,9 @@ template <int K> struct DwCfg {
     static constexpr int WPS = K >= 11 ? 2 : (K >= 5 ? 3 : 4);  // waves per SIMD the register budget allows
 };
 
-template <typename T, int K, int INOP>
+// WU: C/4 is a multiple of 64, so every wave lies inside one item lane: the item index (and with it every time bound and base
+// pointer) is wave-uniform and is kept in scalar registers -> scalar loop control instead of exec-mask branches per step
+template <typename T, int K, int INOP, bool WU>
 __global__ __launch_bounds__(256, DwCfg<K>::WPS) void dwconv_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ w,
                                                                             T* __restrict__ dx, float* __restrict__ part,
                                                                             int B, int Tn, int C, int padl, int seg_len) {
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(256, DwCfg<K>::WPS) void dwconv_bwd_fused_kernel(co
     constexpr int LB = DwCfg<K>::LB;
     const int tid = threadIdx.x;
     const int cg = C >> 2, lanes = 256 / cg;
-    const int c4 = tid % cg, il = tid / cg;
+    const int c4 = tid % cg;
+    const int il = WU ? __builtin_amdgcn_readfirstlane(tid / cg) : tid / cg;
     const int ch = c4 * 4;
     const int Cin = (INOP == DWIN_GLU) ? 2 * C : C;
     const int nseg = (Tn + seg_len - 1) / seg_len;
@@ -198,9 +201,10 @@ static int run_dw_fused(int inop, const T* dy, const T* x, const float* w, T* dx
     if (grid > max_rows) grid = max_rows;
     if (grid > 512) grid = 512;
     const size_t sh = (size_t)(k + 1) * C * sizeof(float);
-#define DWF(KK, OP) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len)
-#define DWFK(OP) switch (k) { case 3: DWF(3, OP); break; case 5: DWF(5, OP); break; case 11: if constexpr (is_bf16_t<T>::value) DWF(11, OP); break; \
-                              default: if constexpr (is_bf16_t<T>::value) DWF(15, OP); break; }
+#define DWF(KK, OP) do { if (cg % 64 == 0) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, true>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len); \
+                         else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, false>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len); } while (0)
+#define DWFK(OP) switch (k) { case 3: DWF(3, OP); break; case 5: DWF(5, OP); break; case 11: if constexpr (is_bf16_t<T>::value) { DWF(11, OP); } break; \
+                              default: if constexpr (is_bf16_t<T>::value) { DWF(15, OP); } break; }
     if (inop == DWIN_SWISH) { DWFK(DWIN_SWISH) } else if (inop == DWIN_GLU) { DWFK(DWIN_GLU) } else { DWFK(DWIN_NONE) }
 #undef DWFK
 #undef DWF
