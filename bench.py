@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU (weak scaling)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -81,7 +83,9 @@ def main():
     from ishara_amd import get_model, parallel
     t_start = time.perf_counter()
 
-    rank, world, local = parallel.init_from_env("nccl")
+    rank, world, local = parallel.init_from_env(args.backend)
+    if args.share_gpu:
+        local = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = f"cuda:{local}"
@@ -113,7 +117,10 @@ def main():
     loss_v = float(loss.item())
 
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
-    prof = model.profile_step(x, y) if rank == 0 else None
+    # one more step with every launch bracketed by HIP events; EVERY rank runs it (the step contains the gradient
+    # all-reduce: a rank that skipped it would leave the others blocked in the collective), rank 0 reports
+    prof = model.profile_step(x, y)
+    parallel.barrier()
     log("profile: " + json.dumps({k: round(v["ms"], 3) for k, v in (prof or {}).items()}))
     if rank != 0:
         return
