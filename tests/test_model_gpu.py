@@ -27,6 +27,9 @@ CFGS = {
     # dim 128 / dh 16 with e=4 squeezeformer (variant notebooks), no Conv1DBlocks
     "variant": dict(dim=128, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(64, 36), B=4,
                     num_conv_per_block=0, squeeze_expansion=4, top_dim=128),
+    # T not a multiple of 64, d=192 (6 heads of 32: off the K=256/512 GEMM fast path), a single clip per batch
+    "ragged": dict(dim=192, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(200, 28), B=1,
+                   num_heads=6, kernel_sizes=[11, 3], num_conv_per_block=1),
 }
 
 
@@ -106,6 +109,43 @@ def test_train_step_parity(name, dtype, dropout):
     for n, rs in ref_stats.items():
         tol = 1e-4 if dtype == "f32" else 3e-2
         assert np.abs(W_after[n] - rs).max() <= tol * (1 + np.abs(rs).max()), n
+
+
+def test_label_edge_cases():
+    """CTC edge cases of c11:1-16: an empty phrase, a phrase filling all 64 label slots, a phrase of one
+    repeated character (needs a blank between every pair) and an infeasible one (more frames needed than given:
+    +inf in Keras; both restatements report > 1e20)."""
+    from oracle import ishara_oracle as O
+    kw = dict(dim=32, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(160, 12), B=5,
+              kernel_sizes=[3], num_conv_per_block=1, num_heads=2)
+    ocfg = _oracle_cfg(kw, 0.0)
+    model = _build(kw, "f32", 0.0)
+    W = _perturb(model)
+    g = np.random.default_rng(5)
+    x = g.standard_normal((5, 160, 12)).astype(np.float32)
+    y = np.full((5, 64), O.BLANK, dtype=np.int64)
+    y[1, :] = g.integers(0, 59, size=64)          # all 64 slots used, no padding
+    y[2, :40] = 7                                 # one repeated character: 79 frames minimum
+    y[3, :1] = 3                                  # single character
+    y[4, :20] = g.integers(0, 59, size=20)
+    loss_t, logits_t = model.loss_and_gradients(x, y, seed=1)
+    torch.cuda.synchronize()
+    ref_loss, ref_logits, ref_grads, _ = O.loss_and_grads(W, x, y, ocfg, training=True, seed=1, dtype=torch.float64)
+    assert np.isfinite(ref_loss)
+    assert abs(float(loss_t.item()) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-4
+    grads = model.get_gradients()
+    gscale = max(float(np.abs(v).max()) for v in ref_grads.values())
+    for n, rg in ref_grads.items():
+        if np.abs(rg).max() < 1e-6 * gscale: continue
+        assert np.abs(grads[n] - rg).max() <= 1e-3 * np.abs(rg).max(), n
+    # per-sample losses, including the empty phrase (all-blank path only)
+    per = model.ctc_loss(y, logits_t).cpu().numpy()
+    ref_per = O.ctc_nll(torch.from_numpy(y), torch.from_numpy(ref_logits).double()).numpy()
+    np.testing.assert_allclose(per, ref_per, rtol=1e-5, atol=1e-4)
+    # a phrase the frames cannot hold (40 repeats need 79 frames, only 78 given): +inf in Keras, huge here and there
+    per_short = model.ctc_loss(y[2:3], logits_t[2:3, :78]).cpu().numpy()
+    ref_short = O.ctc_nll(torch.from_numpy(y[2:3]), torch.from_numpy(ref_logits[2:3, :78]).double()).numpy()
+    assert per_short[0] > 1e20 and ref_short[0] > 1e20
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
