@@ -1152,6 +1152,31 @@ DEVI bf16x8 tr_frag(const char* tile, int lb, int s, int lane) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+typedef __attribute__((ext_vector_type(2))) unsigned tn_u32x2;
+struct TrFrags { u32x4 a[4], b[4]; };
+// fragment reads of the A (offset 0) and B (offset 8192) tiles of ring slot SLOT, as inline asm (see the kernel comment)
+template <int SLOT>
+DEVI void tr_read_asm(const unsigned (&fa)[4], const unsigned (&fb)[4], TrFrags& f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        tn_u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(fa[i]), "n"(SLOT * TR_STAGE));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(fa[i]), "n"(SLOT * TR_STAGE + 1024));
+        f.a[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        tn_u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(fb[j]), "n"(SLOT * TR_STAGE + 8192));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(fb[j]), "n"(SLOT * TR_STAGE + 8192 + 1024));
+        f.b[j] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+}
+// the reads above have landed: the fragments pass through the wait so that their consumers are ordered behind it
+DEVI void tr_wait(TrFrags& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]));
+}
+
 template <int DBG>      // DBG = 1: the ablation bits of tools/gemm_ablate.py are honoured (kept out of the production loop)
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                          float* __restrict__ out, float* __restrict__ dbias,
@@ -1185,10 +1210,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // Software pipeline over the 32-row stages (ring of 4 x 16 KB): at iteration mc the MFMAs of stage mc run from
-    // fragments already in registers while the transposing LDS reads of stage mc+1 are in flight, and stages mc+2 .. mc+4
-    // are in flight from L2/HBM (the slot of stage mc is free as soon as every wave has passed this iteration's barrier,
-    // because its fragments were read during iteration mc-1).
+    // Software pipeline over the 32-row stages (ring of 4 x 16 KB, slots addressed statically: the loop is unrolled by 4):
+    // at step mc the MFMAs of stage mc run from fragments already in registers while the transposing LDS reads of stage
+    // mc+1 are in flight into the OTHER fragment set (ping-pong, no copies), and stages mc+2 .. mc+4 are in flight from
+    // L2/HBM (the slot of stage mc is free as soon as every wave has passed this step's barrier, because its fragments
+    // were read and waited for during step mc-1).
+    // The fragment reads are inline asm: for the ds_read_tr builtin hipcc puts `s_waitcnt vmcnt(0)` in front of the reads
+    // (it cannot tell them from the LDS-DMA writes in flight) and `lgkmcnt(0)` in front of the MFMAs, which serialises
+    // the DMA of three stages, the LDS reads and the MFMAs of every step.
     // DMA source pointers of this lane for the NEXT stage to issue (advanced by 32 rows per issue: no 64-bit address
     // arithmetic in the loop); stages are always issued in order 0, 1, 2, ...
     const bf16* pa[2];
@@ -1204,71 +1233,86 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         }
     }
     const size_t stepA = (size_t)TR_ROWS * Ka, stepB = (size_t)TR_ROWS * Nb;
-    auto issue_stage = [&](int st) {
-        if (st < nmc && !(DBG != 0 && (dbg & 4) != 0)) {
-            char* stage = smem + (st & (TR_NSTAGE - 1)) * TR_STAGE;
+    // LDS byte addresses of this lane's fragment reads in slot 0 (lane (g,q,p) addresses row 8g+q, +4 rows at +1024)
+    unsigned fa[4], fb[4];
+    {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, r0 = 8 * g + q;
+        const unsigned base = (unsigned)(uintptr_t)smem + r0 * 256 + (pp << 3);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int pc = wid + 4 * u;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[u],
-                                                 (__attribute__((address_space(3))) void*)(stage + pc * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[u],
-                                                 (__attribute__((address_space(3))) void*)(stage + 8192 + pc * 1024), 16, 0, 0);
-                pa[u] += stepA; pb[u] += stepB;
-            }
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = base + (((wr * 4 + i) ^ tr_f(r0)) << 5);
+            fb[i] = base + (((wc * 4 + i) ^ tr_f(r0)) << 5);
         }
-    };
-    auto read_frags = [&](int st, bf16x8 (&a)[4], bf16x8 (&b)[4]) {
-        const char* sa = smem + (st & (TR_NSTAGE - 1)) * TR_STAGE;
-        const char* sb = sa + 8192;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = (DBG != 0 && (dbg & 2) != 0) ? bf16x8{} : tr_frag(sa, wr * 4 + i, 0, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = (DBG != 0 && (dbg & 2) != 0) ? bf16x8{} : tr_frag(sb, wc * 4 + j, 0, lane);
-    };
+    }
+    const bool no_dma = DBG != 0 && (dbg & 4) != 0, no_frag = DBG != 0 && (dbg & 2) != 0, no_mma = DBG != 0 && (dbg & 1) != 0;
     const int nmc_run = (DBG != 0 && (dbg & 16) != 0) ? 0 : nmc;
-    bf16x8 a_cur[4], b_cur[4], a_nxt[4], b_nxt[4];
+    TrFrags P, Q;
 #pragma unroll
-    for (int st = 0; st < TR_NSTAGE; ++st) issue_stage(st);
+    for (int i = 0; i < 4; ++i) { P.a[i] = P.b[i] = Q.a[i] = Q.b[i] = u32x4{0u, 0u, 0u, 0u}; }
+
+#define TN_ISSUE(SLOT, ST)                                                                                               \
+    if ((ST) < nmc && !no_dma) {                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                  \
+            const int pc = wid + 4 * u;                                                                                  \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[u],                       \
+                                             (__attribute__((address_space(3))) void*)(smem + (SLOT) * TR_STAGE + pc * 1024), 16, 0, 0);        \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[u],                       \
+                                             (__attribute__((address_space(3))) void*)(smem + (SLOT) * TR_STAGE + 8192 + pc * 1024), 16, 0, 0); \
+            pa[u] += stepA; pb[u] += stepB;                                                                              \
+        }                                                                                                                \
+    }
+#define TN_COMPUTE(CUR)                                                                                                  \
+    if (want_bias) {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
+            float t = 0.f;                                                                                               \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                \
+                t += __uint_as_float(CUR.b[j][e] << 16) + __uint_as_float(CUR.b[j][e] & 0xffff0000u);                    \
+            csum[j] += t;                                                                                                \
+        }                                                                                                                \
+    }                                                                                                                    \
+    if (!no_mma) {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, CUR.a[i]), __builtin_bit_cast(bf16x8, CUR.b[j]), acc[i][j], 0, 0, 0); \
+    } else {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i][0][0] += __uint_as_float(CUR.a[i][0]) + __uint_as_float(CUR.b[i][0]); \
+    }
+    // one step: FULL = at least two younger stages are in flight behind stage mc+U+1 (steady state: no branches)
+#define TN_STEP(U, CUR, NXT, FULL)                                                                                       \
+    if (FULL || mc + (U) < nmc_run) {                                                                                    \
+        if (FULL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                       \
+        else {                                                                                                           \
+            const int younger = min(nmc - 1, mc + (U) + 3) - (mc + (U) + 1);                                             \
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                           \
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                      \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        }                                                                                                                \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+        TN_ISSUE(U, mc + (U) + TR_NSTAGE)                                                                                \
+        if ((FULL || mc + (U) + 1 < nmc_run) && !no_frag) tr_read_asm<((U) + 1) & 3>(fa, fb, NXT);                       \
+        TN_COMPUTE(CUR)                                                                                                  \
+        tr_wait(NXT);                                                                                                    \
+    }
+
+    TN_ISSUE(0, 0) TN_ISSUE(1, 1) TN_ISSUE(2, 2) TN_ISSUE(3, 3)
+    int mc = 0;
     if (nmc_run > 0) {
         // stage 0 landed: its 4 DMA are the oldest of up to 16
         if (nmc >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        read_frags(0, a_cur, b_cur);
-    }
-    for (int mc = 0; mc < nmc_run; ++mc) {
-        // stage mc+1 landed; the DMA of stages mc+2, mc+3 (4 per wave each) may stay in flight
-        const int younger = min(nmc - 1, mc + 3) - (mc + 1);        // stages issued after mc+1 so far
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's reads of stage mc are in registers
-        __builtin_amdgcn_s_barrier();
-        issue_stage(mc + TR_NSTAGE);                                 // into the slot of stage mc
-        if (mc + 1 < nmc_run) read_frags(mc + 1, a_nxt, b_nxt);
-        if (want_bias) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t += (float)b_cur[j][e];
-                csum[j] += t;
-            }
+        if (!no_frag) tr_read_asm<0>(fa, fb, P);
+        tr_wait(P);
+        for (; mc + 7 <= nmc_run; mc += 4) {          // steps mc .. mc+3 all have stages mc+U+3 <= nmc-1 behind them
+            TN_STEP(0, P, Q, true) TN_STEP(1, Q, P, true) TN_STEP(2, P, Q, true) TN_STEP(3, Q, P, true)
         }
-        if (!(DBG != 0 && (dbg & 1) != 0)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][0][0] += (float)a_cur[i][0] + (float)b_cur[i][0];
+        for (; mc < nmc_run; mc += 4) {
+            TN_STEP(0, P, Q, false) TN_STEP(1, Q, P, false) TN_STEP(2, P, Q, false) TN_STEP(3, Q, P, false)
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a_cur[i] = a_nxt[i]; b_cur[i] = b_nxt[i]; }
     }
+#undef TN_STEP
+#undef TN_COMPUTE
+#undef TN_ISSUE
 
     // ---- write this split's 128x128 partial to its fp32 slab: each wave transposes its 64x64 accumulator block through
     // a private LDS stage (two 32-row passes) so that every store instruction writes 4 rows x 256 contiguous bytes
@@ -1441,8 +1485,11 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
     int want = max(1, 512 / tiles);                       // two 64 KB-LDS workgroups per CU
     const int maxs = max(1, M / 256);                     // at least 8 tiles per split
     if (want > maxs) want = maxs;
-    const int rps = ((M + want - 1) / want + TR_ROWS - 1) / TR_ROWS * TR_ROWS;
-    const int splits = (M + rps - 1) / rps;
+    if (want > 8) want &= ~7;                             // a multiple of 8 keeps the XCD-aware (tile, split) mapping: 12 tiles x 42 splits ran 102 us, x 40: see DESIGN.md
+    int rps = ((M + want - 1) / want + TR_ROWS - 1) / TR_ROWS * TR_ROWS;
+    int splits = (M + rps - 1) / rps;
+    while (want > 8 && (splits & 7) != 0 && rps > TR_ROWS) { rps -= TR_ROWS; splits = (M + rps - 1) / rps; if (splits > 512) break; }
+    if (splits > 512) { rps = ((M + want - 1) / want + TR_ROWS - 1) / TR_ROWS * TR_ROWS; splits = (M + rps - 1) / rps; }
     float* bias_slab = dbias ? slab + (size_t)Ka * Nb : nullptr;        // bias partials sit right behind each split's weight partial
     if (g_tn_phase != 2)
     {
