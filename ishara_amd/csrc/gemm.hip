@@ -1390,17 +1390,17 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s);
-// Slab sums without atomics: a workgroup owns 32 columns; thread (cq = tid&7, sl = tid>>3) sums the slabs sl, sl+SL, ... of
-// column quad cq with 8 loads in flight, the SL slab lanes are combined by wave shuffles + LDS, and ONE thread adds the
-// total to out; one launch serves two outputs (columns [0, n0) -> out0, [n0, n) -> out1).  Same-address atomics were the
-// whole cost of the previous reducer (2-way 80 us, 4-way 83 us, 8-way 106 us per wgrad including the GEMM).
-template <int SL>     // slab lanes per workgroup: 128 (narrow slabs: 1024 threads own 32 columns) or 32 (wide slabs: 256 threads)
-__global__ __launch_bounds__(8 * SL) void reduce_slabs_cols_kernel(const float* __restrict__ slab, float* __restrict__ out0, float* __restrict__ out1,
-                                                                   int n0, int n, int splits, size_t stride) {
-    constexpr int NWV = SL / 8;            // waves
-    __shared__ float4 red[NWV][8];
-    const int tid = threadIdx.x, cq = tid & 7, sl = tid >> 3;
-    const int col = blockIdx.x * 32 + cq * 4;
+// Slab sums without atomics: a workgroup of 256 threads owns 4*CQ columns; thread (cq = tid % CQ, sl = tid / CQ) sums the
+// slabs sl, sl+SL, ... of column quad cq with 8 loads in flight (SL = 8 covers 64 splits in one pass), the SL partial
+// rows are combined through LDS in a fixed order, and ONE thread adds the total to out; one launch serves two outputs
+// (columns [0, n0) -> out0, [n0, n) -> out1).  Same-address atomics were the whole cost of the first reducer (2-way 80 us,
+// 4-way 83 us, 8-way 106 us per wgrad including the GEMM); 128 slab lanes with one load each ran 10.5 us per 32 MB.
+template <int SL, int CQ>
+__global__ __launch_bounds__(SL * CQ) void reduce_slabs_cols_kernel(const float* __restrict__ slab, float* __restrict__ out0, float* __restrict__ out1,
+                                                                    int n0, int n, int splits, size_t stride) {
+    __shared__ float4 red[SL][CQ];
+    const int tid = threadIdx.x, cq = tid % CQ, sl = tid / CQ;
+    const int col = blockIdx.x * (CQ * 4) + cq * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < n) {
         for (int s0 = sl; s0 < splits; s0 += SL * 8) {
@@ -1414,20 +1414,20 @@ __global__ __launch_bounds__(8 * SL) void reduce_slabs_cols_kernel(const float* 
             for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
     }
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-        acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-    }
-    if ((tid & 63) < 8) red[tid >> 6][cq] = acc;
+    red[sl][cq] = acc;
     __syncthreads();
-    if (tid < 8 && col < n) {
-        float4 t = red[0][tid];
+    if (sl == 0 && col < n) {
+        float4 t = red[0][cq];
 #pragma unroll
-        for (int w = 1; w < NWV; ++w) { t.x += red[w][tid].x; t.y += red[w][tid].y; t.z += red[w][tid].z; t.w += red[w][tid].w; }
+        for (int w = 1; w < SL; ++w) { t.x += red[w][cq].x; t.y += red[w][cq].y; t.z += red[w][cq].z; t.w += red[w][cq].w; }
         float* dst = col < n0 ? out0 + col : out1 + (col - n0);      // parameter blocks of the flat gradient are only 4-byte aligned
         dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;
     }
+}
+static void launch_reduce_cols(const float* slab, float* out0, float* out1, int n0, int n, int splits, size_t stride, hipStream_t s) {
+    if (n <= 2048) hipLaunchKernelGGL((reduce_slabs_cols_kernel<64, 4>), dim3((n + 15) / 16), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride);   // narrow, many partial rows (LayerNorm, dwconv)
+    else if (splits <= 64) hipLaunchKernelGGL((reduce_slabs_cols_kernel<8, 32>), dim3((n + 127) / 128), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride);
+    else hipLaunchKernelGGL((reduce_slabs_cols_kernel<16, 16>), dim3((n + 63) / 64), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride);
 }
 
 static bool reduce_cols_ok(const float* slab, const float* out0, const float* out1, int n0, int n, size_t stride) {
@@ -1437,21 +1437,13 @@ static bool reduce_cols_ok(const float* slab, const float* out0, const float* ou
 
 // out0[0..n0) += column sums of slab[:, 0..n0), out1[0..n1) += column sums of slab[:, n0..n0+n1)   (slab rows `stride` floats apart)
 void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s) {
-    if (reduce_cols_ok(slab, out0, out1, n0, n0 + n1, stride)) {
-        if (n0 + n1 <= 2048) hipLaunchKernelGGL(reduce_slabs_cols_kernel<128>, dim3((n0 + n1 + 31) / 32), dim3(1024), 0, s, slab, out0, out1, n0, n0 + n1, splits, stride);
-        else hipLaunchKernelGGL(reduce_slabs_cols_kernel<32>, dim3((n0 + n1 + 31) / 32), dim3(256), 0, s, slab, out0, out1, n0, n0 + n1, splits, stride);
-        return;
-    }
+    if (reduce_cols_ok(slab, out0, out1, n0, n0 + n1, stride)) { launch_reduce_cols(slab, out0, out1, n0, n0 + n1, splits, stride, s); return; }
     launch_reduce_slabs(slab, out0, n0, splits, stride, s);
     if (out1 && n1 > 0) launch_reduce_slabs(slab + n0, out1, n1, splits, stride, s);
 }
 
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s) {
-    if (reduce_cols_ok(slab, out, nullptr, n, n, stride)) {
-        if (n <= 2048) hipLaunchKernelGGL(reduce_slabs_cols_kernel<128>, dim3((n + 31) / 32), dim3(1024), 0, s, slab, out, (float*)nullptr, n, n, splits, stride);
-        else hipLaunchKernelGGL(reduce_slabs_cols_kernel<32>, dim3((n + 31) / 32), dim3(256), 0, s, slab, out, (float*)nullptr, n, n, splits, stride);
-        return;
-    }
+    if (reduce_cols_ok(slab, out, nullptr, n, n, stride)) { launch_reduce_cols(slab, out, nullptr, n, n, splits, stride, s); return; }
     const int gx = (n + 1023) / 1024;
     int gy = 1;                                            // split groups: enough workgroups to fill the chip
     while (gx * gy < 256 && gy * 16 <= splits) gy *= 2;     // same-address atomics are expensive: 8-way 106 us, 4-way 83 us per wgrad (incl. GEMM)

@@ -155,6 +155,21 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
     const TC* resid = reinterpret_cast<const TC*>(ea.resid);
     const TC* aux = reinterpret_cast<const TC*>(ea.aux);
 
+    // Everything loaded before the loop (A fragments, per-row constants) passes through an empty asm here: hipcc then waits
+    // for those loads ONCE, in front of the loop.  Otherwise its wait-counter model still sees them pending at the loop
+    // header and puts `s_waitcnt vmcnt(0)` in front of the first MFMA of every step -- behind the DMA of the next stage,
+    // which then never overlaps this wave's MFMAs.
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            as_u32x4 t = __builtin_bit_cast(as_u32x4, a[i][kt]);
+            asm volatile("" : "+v"(t));
+            a[i][kt] = __builtin_bit_cast(bf16x8, t);
+        }
+        asm volatile("" : "+v"(rsc[i]));
+    }
+
     int slot = 0;
     for (int s = 0; s < nsteps; ++s) {
         // ---- T1: stage s has landed.  Younger operations that may stay in flight (in-order VM counter): the DMAs of
