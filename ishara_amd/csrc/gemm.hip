@@ -1470,11 +1470,15 @@ size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM) {
 
 int g_force_tn_regstage = 0;   // tests: force the register-transposing TN kernel
 
+int g_tn_blocks = 0;
 int g_tn_phase = 0;            // 0: GEMM + slab sums; 1: GEMM kernel only; 2: slab sums only (the model profiles the two separately)
 
 static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s) {
     const int tiles = (Ka / 128) * (Nb / 128);
-    int want = max(1, 512 / tiles);                       // two 64 KB-LDS workgroups per CU
+    // workgroups: one per CU for up to 8 tiles (same kernel time as two per CU, half the slab bytes: the slab sums go
+    // 9.6 -> 7.3 us), two per CU for 12+ tiles (N = 768: 61 vs 72 us); g_tn_blocks != 0 overrides (tools/tn_ablate.py)
+    const int blocks = g_tn_blocks ? g_tn_blocks : (tiles <= 8 ? 256 : 512);
+    int want = max(1, blocks / tiles);
     const int maxs = max(1, M / 256);                     // at least 8 tiles per split
     if (want > maxs) want = maxs;
     if (want > 8) want &= ~7;                             // a multiple of 8 keeps the XCD-aware (tile, split) mapping: 12 tiles x 42 splits ran 102 us, x 40: see DESIGN.md

@@ -7,6 +7,9 @@ import numpy as np, torch
 from ishara_amd import get_model
 import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+if len(sys.argv) > 2:      # debug switches of ishara_debug_force_regstage (e.g. 16384: 256 wgrad workgroups)
+    from ishara_amd import _lib
+    _lib.load().ishara_debug_force_regstage(int(sys.argv[2]))
 model = get_model(**bench.MODEL_KW, dtype="bf16", max_batch=B, device="cuda:0", seed=0)
 g = np.random.default_rng(1)
 x = torch.from_numpy(g.standard_normal((B, 384, 224)).astype(np.float32)).cuda()
@@ -25,3 +28,8 @@ for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0
     print(f"{k:44s} {v['launches']:4d} {v['ms']:8.3f} {avg:8.1f} {gbs:8.0f} {tf:7.1f}")
 print(f"{'total':44s} {'':4s} {tot:8.3f}")
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    model.train_on_batch(x, y)
+torch.cuda.synchronize(); print(f"wall ms/step (10 steps): {(time.perf_counter() - t0) * 100:.2f}")

@@ -12,7 +12,7 @@ for (M, K, N) in [(98304, 256, 512), (98304, 512, 256), (98304, 256, 768), (9830
     sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
     scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
     res = {}
-    V = {"tr": 0, "nomma": 1, "nofrag": 2, "nomma-nofrag": 3, "noload": 4, "noepi": 8, "noloop": 16, "nothing": 7 | 8}
+    V = {"tr": 0, "tr256": 1 << 6, "tr512": 2 << 6, "tr768": 3 << 6, "nomma": 1, "nofrag": 2, "nomma-nofrag": 3, "noload": 4, "noepi": 8, "noloop": 16, "nothing": 7 | 8}
     for rnd in range(3):
         for name, bits in V.items():
             lib.ishara_debug_force_regstage(bits << 8)
