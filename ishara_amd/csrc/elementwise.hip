@@ -943,24 +943,35 @@ int launch_sample_reduce(int dt, const void* dy, const void* other, const float*
 // =====================================================================================
 // BatchNorm finalize from per-sample sums [nb, C] (fp64 accumulation across samples)
 // =====================================================================================
-// block = 64 channels x 16 sample lanes; fp64 accumulation across samples
-#define FIN_BL 16
+// block = FIN_CL channels x FIN_BL sample lanes (1024 threads); fp64 accumulation across samples.  16 x 64 instead of
+// 64 x 16: C = 512 gives 32 workgroups with 4 samples per thread instead of 8 with 16 (these [B, C] passes are latency
+// bound).  A wave holds 4 sample lanes x 16 channels: two shuffles fold the
+// lanes, then the 16 waves are summed through LDS in a fixed order.
+#define FIN_CL 16
+#define FIN_BL 64
+#define FIN_NW (FIN_CL * FIN_BL / 64)
+DEVI double fin_fold(double v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nb, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ mmean, float* __restrict__ mvar, int training,
                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ bsh, int C) {
-    __shared__ double rs_[FIN_BL][64], rq_[FIN_BL][64];
-    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double rs_[FIN_NW][FIN_CL], rq_[FIN_NW][FIN_CL];
+    const int cl = threadIdx.x & (FIN_CL - 1), bl = threadIdx.x / FIN_CL, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * FIN_CL + cl;
     double s = 0.0, q = 0.0;
     if (training && c < C)
         for (int b = bl; b < nb; b += FIN_BL) { s += (double)ssum[(size_t)b * C + c]; q += (double)ssq[(size_t)b * C + c]; }
-    rs_[bl][cl] = s; rq_[bl][cl] = q;
+    s = fin_fold(s); q = fin_fold(q);
+    if ((threadIdx.x & 63) < FIN_CL) { rs_[wv][cl] = s; rq_[wv][cl] = q; }
     __syncthreads();
     if (bl != 0 || c >= C) return;
     float mu, var;
     if (training) {
-        for (int i = 1; i < FIN_BL; ++i) { s += rs_[i][cl]; q += rq_[i][cl]; }
+        for (int i = 1; i < FIN_NW; ++i) { s += rs_[i][cl]; q += rq_[i][cl]; }
         const double m = s / (double)count;
         double v = q / (double)count - m * m;
         if (v < 0.0) v = 0.0;
@@ -977,7 +988,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count, const float* gamma, const float* beta,
                           float eps, float momentum, float* moving_mean, float* moving_var, int training,
                           float* mean, float* rstd, float* a, float* b, int C, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64 * FIN_BL), 0, s, ssum, ssq, nb, count, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, ssum, ssq, nb, count, gamma, beta, eps, momentum,
                        moving_mean, moving_var, training, mean, rstd, a, b, C);
     return LAUNCH_OK();
 }
@@ -1119,15 +1130,15 @@ __global__ __launch_bounds__(256) void eca_bwd_sample_kernel(const float* __rest
     if (threadIdx.x < 5) atomicAdd(dw5 + threadIdx.x, wred[threadIdx.x][0] + wred[threadIdx.x][1] + wred[threadIdx.x][2] + wred[threadIdx.x][3]);
 }
 
-// step 2, per channel (64 channels x 16 sample lanes per block): dgamma, dbeta, Fc; E[b,c] <- dgn/T - dbeta/Mtot
+// step 2, per channel (FIN_CL channels x FIN_BL sample lanes per block): dgamma, dbeta, Fc; E[b,c] <- dgn/T - dbeta/Mtot
 __global__ __launch_bounds__(1024) void eca_bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ gap,
                                           const float* __restrict__ sg, const float* __restrict__ mean, const float* __restrict__ rstd,
                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ E, float* __restrict__ Fc,
                                           int B, int Tn, int C) {
-    __shared__ double rg_[FIN_BL][64], rb_[FIN_BL][64];
-    __shared__ float eb_[64];
-    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double rg_[FIN_NW][FIN_CL], rb_[FIN_NW][FIN_CL];
+    __shared__ float eb_[FIN_CL];
+    const int cl = threadIdx.x & (FIN_CL - 1), bl = threadIdx.x / FIN_CL, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * FIN_CL + cl;
     const bool act = c < C;
     const float invT = 1.f / (float)Tn, mu = act ? mean[c] : 0.f, rs = act ? rstd[c] : 0.f;
     double dg = 0.0, db = 0.0;
@@ -1138,11 +1149,12 @@ __global__ __launch_bounds__(1024) void eca_bn_bwd_channel_kernel(const float* _
             dg += (double)(sg[i] * S2[i] + E[i] * ghat);
             db += (double)(sg[i] * S1[i] + E[i]);
         }
-    rg_[bl][cl] = dg; rb_[bl][cl] = db;
+    dg = fin_fold(dg); db = fin_fold(db);
+    if ((threadIdx.x & 63) < FIN_CL) { rg_[wv][cl] = dg; rb_[wv][cl] = db; }
     __syncthreads();
     const float mtot = (float)B * (float)Tn;
     if (bl == 0 && act) {
-        for (int i = 1; i < FIN_BL; ++i) { dg += rg_[i][cl]; db += rb_[i][cl]; }
+        for (int i = 1; i < FIN_NW; ++i) { dg += rg_[i][cl]; db += rb_[i][cl]; }
         dgamma[c] += (float)dg;
         dbeta[c] += (float)db;
         Fc[c] = (float)dg / mtot;
@@ -1159,22 +1171,23 @@ int launch_eca_bn_bwd_finalize(const float* S1, const float* S2, const float* ga
                                const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
                                float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, int B, int T, int C, hipStream_t s) {
     hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B), dim3(256), 2 * (C + 4) * sizeof(float), s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5, C);
-    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + 63) / 64), dim3(64 * FIN_BL), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, B, T, C);
+    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, B, T, C);
     return LAUNCH_OK();
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, float* __restrict__ dgamma,
                                       float* __restrict__ dbeta, float* __restrict__ Ecol, float* __restrict__ Fc, int B, int Tn, int C) {
-    __shared__ double rg_[FIN_BL][64], rb_[FIN_BL][64];
-    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double rg_[FIN_NW][FIN_CL], rb_[FIN_NW][FIN_CL];
+    const int cl = threadIdx.x & (FIN_CL - 1), bl = threadIdx.x / FIN_CL, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * FIN_CL + cl;
     double dg = 0.0, db = 0.0;
     if (c < C)
         for (int b = bl; b < B; b += FIN_BL) { dg += (double)S2[(size_t)b * C + c]; db += (double)S1[(size_t)b * C + c]; }
-    rg_[bl][cl] = dg; rb_[bl][cl] = db;
+    dg = fin_fold(dg); db = fin_fold(db);
+    if ((threadIdx.x & 63) < FIN_CL) { rg_[wv][cl] = dg; rb_[wv][cl] = db; }
     __syncthreads();
     if (bl != 0 || c >= C) return;
-    for (int i = 1; i < FIN_BL; ++i) { dg += rg_[i][cl]; db += rb_[i][cl]; }
+    for (int i = 1; i < FIN_NW; ++i) { dg += rg_[i][cl]; db += rb_[i][cl]; }
     const float mtot = (float)B * (float)Tn;
     dgamma[c] += (float)dg;
     dbeta[c] += (float)db;
@@ -1184,7 +1197,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_channel_kernel(const float* __res
 
 int launch_bn_bwd_finalize(const float* S1, const float* S2, float* dgamma, float* dbeta, float* Ecol, float* Fc,
                            int B, int T, int C, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_channel_kernel, dim3((C + 63) / 64), dim3(64 * FIN_BL), 0, s, S1, S2, dgamma, dbeta, Ecol, Fc, B, T, C);
+    hipLaunchKernelGGL(bn_bwd_channel_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, S1, S2, dgamma, dbeta, Ecol, Fc, B, T, C);
     return LAUNCH_OK();
 }
 
