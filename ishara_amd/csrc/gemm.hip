@@ -1473,7 +1473,7 @@ int g_force_tn_regstage = 0;   // tests: force the register-transposing TN kerne
 int g_tn_blocks = 0;
 int g_tn_phase = 0;            // 0: GEMM + slab sums; 1: GEMM kernel only; 2: slab sums only (the model profiles the two separately)
 
-static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s) {
+static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s, int ka_valid) {
     const int tiles = (Ka / 128) * (Nb / 128);
     // workgroups: one per CU for up to 8 tiles (same kernel time as two per CU, half the slab bytes: the slab sums go
     // 9.6 -> 7.3 us), two per CU for 12+ tiles (N = 768: 61 vs 72 us); g_tn_blocks != 0 overrides (tools/tn_ablate.py)
@@ -1493,7 +1493,7 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
         else hipLaunchKernelGGL(gemm_tn_tr_kernel<0>, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0);
     }
     if (g_tn_phase != 1)
-        launch_reduce_slabs2(slab, out, Ka * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s);
+        launch_reduce_slabs2(slab, out, ka_valid * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s);   // rows >= ka_valid of A are zero padding (no bias then)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1518,8 +1518,9 @@ static int run_tn(int opA, int opB, const void* A, const void* B, float* out, fl
 
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
-                   const OpArgs& oa, const OpArgs& ob, hipStream_t s) {
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid) {
     if (M <= 0 || Ka <= 0 || Nb <= 0) { ishara_set_error("gemm_tn: bad shape"); return -1; }
+    if (ka_valid <= 0) ka_valid = Ka;
     if ((dtA == DT_BF16 && Ka % 8 != 0) || (dtA == DT_F32 && Ka % 4 != 0) || (dtB == DT_BF16 && Nb % 8 != 0) || (dtB == DT_F32 && Nb % 4 != 0) ||
         ((uintptr_t)A) % 16 != 0 || ((uintptr_t)B) % 16 != 0) {
         ishara_set_error("gemm_tn: operand rows must be 16-byte aligned (Ka=%d Nb=%d)", Ka, Nb); return -1;
@@ -1527,7 +1528,11 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
     if (dtA == DT_F32 && dtB == DT_F32 && dtM == DT_F32) return run_tn<float, float, float>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && opA == OP_NONE && opB == OP_NONE && M % 64 == 0 && Ka % 128 == 0 && Nb % 128 == 0 &&
         M >= 256 && !g_force_tn_regstage)
-        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s);
+    {
+        if (ka_valid < Ka && dbias) { ishara_set_error("gemm_tn: padded A columns with a bias gradient"); return -1; }
+        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid);
+    }
+    if (ka_valid != Ka) { ishara_set_error("gemm_tn: padded A columns need the bf16 transposed-read kernel (M %% 64, Ka %% 128, Nb %% 128)"); return -1; }
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<bf16, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
     if (dtA == DT_F32 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<float, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
     if (dtA == DT_BF16 && dtB == DT_F32 && dtM == DT_BF16) return run_tn<bf16, float, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
@@ -1596,6 +1601,27 @@ int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt,
     dim3 grid((N + 31) / 32, (K + 31) / 32);
     if (dtM == DT_BF16) hipLaunchKernelGGL(make_shadow_kernel<bf16>, grid, dim3(256), 0, s, W, K, N, (bf16*)Wt, ldt, (bf16*)Wn, ldn);
     else hipLaunchKernelGGL(make_shadow_kernel<float>, grid, dim3(256), 0, s, W, K, N, (float*)Wt, ldt, (float*)Wn, ldn);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// xb[M, Kp] (bf16) = x[M, F] (f32) zero padded: the stem's input rows as an MFMA operand (the f32-A GEMM kernels round the
+// same way while staging; done once here, the stem Dense and its wgrad run on the bf16 fast paths with K = Kp)
+__global__ __launch_bounds__(256) void pack_rows_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ xb, int M, int F, int Kp) {
+    const int cpr = Kp >> 3;                                   // 16-byte output chunks per row
+    const size_t total = (size_t)M * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / cpr;
+        const int c0 = (int)(i - row * cpr) * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* src = x + row * F + c0;
+        if (c0 + 4 <= F) { const float4 a = *reinterpret_cast<const float4*>(src); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+        if (c0 + 8 <= F) { const float4 a = *reinterpret_cast<const float4*>(src + 4); v[4] = a.x; v[5] = a.y; v[6] = a.z; v[7] = a.w; }
+        *reinterpret_cast<u32x4*>(xb + row * Kp + c0) = pack_chunk<bf16, 8>(v);
+    }
+}
+int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s) {
+    if (F % 4 != 0 || Kp % 8 != 0 || Kp < F || ((uintptr_t)x) % 16 != 0) { ishara_set_error("pack_rows_bf16: F=%d Kp=%d unsupported", F, Kp); return -1; }
+    hipLaunchKernelGGL(pack_rows_bf16_kernel, dim3(2048), dim3(256), 0, s, x, (bf16*)xb, M, F, Kp);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -360,7 +360,7 @@ static int as_inst_mask(bool c_bf16, int mask) {
     if (!c_bf16) return mask == 0 ? 0 : AS_ALL;
     switch (mask) {
         case 0: case AS_RESID: case AS_RESID | AS_ROWSCALE: case AS_RESID | AS_DROP: case AS_ACT | AS_PREOUT: case AS_ACT | AS_PREOUT | AS_DROP:
-        case AS_ACT | AS_DROP: case AS_ACT: case AS_DACT: case AS_DACT | AS_DROP: case AS_QKV: return mask;
+        case AS_ACT | AS_DROP: case AS_ACT: case AS_DACT: case AS_DACT | AS_DROP: case AS_QKV: case AS_ADDTAB: return mask;
         default: return AS_ALL;
     }
 }
@@ -388,6 +388,7 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
             case AS_DACT: AS_LAUNCH(AS_DACT); break;                                             // dgrad through swish / relu
             case AS_DACT | AS_DROP: AS_LAUNCH(AS_DACT | AS_DROP); break;
             case AS_QKV: AS_LAUNCH(AS_QKV); break;
+            case AS_ADDTAB: AS_LAUNCH(AS_ADDTAB); break;
             default: AS_LAUNCH(AS_ALL); break;
         }
     } else {

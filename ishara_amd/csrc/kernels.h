@@ -50,9 +50,12 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
 size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM);
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
-                   const OpArgs& oa, const OpArgs& ob, hipStream_t s);
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0);   // ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows
+// xb[M, Kp] (bf16) = x[M, F] (f32), zero padded to Kp columns (F % 4 == 0, Kp % 8 == 0)
+int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s);
 
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
+extern int g_force_tn_regstage;   // tests: 1 forces the register-transposing TN kernel
 extern int g_tn_phase;   // 0 GEMM + slab sums, 1 GEMM kernel only, 2 slab sums only
 const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb);
 

@@ -142,6 +142,7 @@ struct ishara_model {
     int64_t n_total = 0, n_train = 0;
     // graph
     DenseW stemW; BNp stem_bn;
+    int stem_kp = 0; Buf stem_xb;      // bf16 model: input rows packed to bf16 [M, stem_kp] (zero padded), 0 = f32-A GEMM path
     Buf stem_h0, stem_out, stem_ssum, stem_ssq, stem_mean, stem_rstd, stem_a, stem_bsh, pe;
     std::vector<ConvBlock> convs;
     std::vector<SqzBlock> sqz;
@@ -304,10 +305,11 @@ static void build_graph(ishara_model* m) {
     m->n_total = off;
 }
 
-static void plan_shadow(ishara_model* m, DenseW& w) {
+static void plan_shadow(ishara_model* m, DenseW& w, int min_ldt = 0) {
     const int bk = m->dt == DT_BF16 ? 64 : 32;
     const size_t es = dt_size(m->dt);
     w.ldt = (int)rup(w.K, bk);
+    if (w.ldt < min_ldt) w.ldt = min_ldt;      // zero-padded K (the shadow arena is zero-filled, the builder writes k < K)
     w.wt = m->alloc(rup(w.N, 128) * (size_t)w.ldt * es).off;
     w.ldn = (int)rup(w.N, bk);
     w.wn = m->alloc(rup(w.K, 128) * (size_t)w.ldn * es).off;
@@ -320,7 +322,8 @@ static void plan_workspace(ishara_model* m) {
     m->cur = 0;
     // ---- shadows first (one contiguous arena that sync_weights zero-fills)
     m->shadow_begin = m->cur;
-    plan_shadow(m, m->stemW);
+    m->stem_kp = (m->dt == DT_BF16 && m->F <= 512) ? (m->F <= 256 ? 256 : 512) : 0;
+    plan_shadow(m, m->stemW, m->stem_kp);
     for (auto& cb : m->convs) { plan_shadow(m, cb.W1); plan_shadow(m, cb.W2); }
     // FFN/MHSA shadows are planned with their activations below; keep the arena contiguous by
     // planning all shadows before any activation:
@@ -334,6 +337,7 @@ static void plan_workspace(ishara_model* m) {
     // ---- stem
     m->pe = m->f32((size_t)T * d);
     m->stem_h0 = m->act(d); m->stem_out = m->act(d);
+    if (m->stem_kp) m->stem_xb = m->alloc(Mx * (size_t)m->stem_kp * 2);
     m->stem_ssum = m->f32((size_t)B * d); m->stem_ssq = m->f32((size_t)B * d);
     m->stem_mean = m->f32(d); m->stem_rstd = m->f32(d); m->stem_a = m->f32(d); m->stem_bsh = m->f32(d);
     for (auto& cb : m->convs) {
@@ -386,6 +390,7 @@ static void plan_workspace(ishara_model* m) {
     m->dse = m->f32((size_t)B * d); m->dgapT = m->f32((size_t)B * d);
     size_t slabf = 0;
     for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > slabf) slabf = f; }
+    if (m->stem_kp) { const size_t f = gemm_tn_slab_floats((int)Mx, m->stem_kp, d, m->dt); if (f > slabf) slabf = f; }
     if (layernorm_bwd_scratch_floats(d) > slabf) slabf = layernorm_bwd_scratch_floats(d);
     if (dwconv_bwd_scratch_floats(2 * maxw, 31) > slabf) slabf = dwconv_bwd_scratch_floats(2 * maxw, 31);
     if (dwconv_fwd_scratch_floats(B, T, 2 * maxw) > slabf) slabf = dwconv_fwd_scratch_floats(B, T, 2 * maxw);
@@ -502,13 +507,13 @@ static int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA,
     CKP(m, gemm_nt_kernel_name(dtA, m->dt, m->dt, aop, dY, M, w.K, w.N, w.ldn, ea), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
     return 0;
 }
-static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M) {
+static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
     // the GEMM kernel and the sums of its split-M slabs are profiled under separate keys (the kernel's key is its rocprof name)
     g_tn_phase = 1;
-    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s));
+    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid));
     g_tn_phase = 2;
-    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s));
+    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid));
     g_tn_phase = 0;
     return 0;
 }
@@ -600,7 +605,12 @@ extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float*
     OpArgs no;
     // ---- stem: Dense(no bias) + PE, BatchNorm(momentum .95)  (c7:13-17)
     EpiArgs es; es.addtab = m->Wf(m->pe); es.tab_period = T;
-    CK(gemm_fwd(m, m->stemW, x, DT_F32, m->W(m->stem_h0), dt, r.M, OP_NONE, no, es));
+    if (m->stem_kp) {       // bf16: pack the input rows once, then the Dense (and its wgrad) run on the bf16 fast paths with K = stem_kp
+        CKP(m, "pack_rows_bf16", (double)r.M * (m->F * 4.0 + m->stem_kp * 2.0), 0, launch_pack_rows_bf16(x, m->W(m->stem_xb), r.M, m->F, m->stem_kp, m->s));
+        DenseW wp = m->stemW; wp.K = m->stem_kp;
+        CK(gemm_fwd(m, wp, m->W(m->stem_xb), dt, m->W(m->stem_h0), dt, r.M, OP_NONE, no, es));
+    } else
+        CK(gemm_fwd(m, m->stemW, x, DT_F32, m->W(m->stem_h0), dt, r.M, OP_NONE, no, es));
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->stem_h0), m->W(m->stem_h0), nullptr, nullptr, m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, T, d, m->s));
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, (float)B * T, m->P(m->stem_bn.gamma), m->P(m->stem_bn.beta), 1e-3f, 0.95f,
                           m->P(m->stem_bn.mm), m->P(m->stem_bn.mv), training, m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->stem_a), m->Wf(m->stem_bsh), d, m->s));
@@ -785,7 +795,11 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
     CKP(m, "bn_bwd_finalize", 0, 0, launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(m->stem_bn.gamma), m->G(m->stem_bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
     CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->stem_a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t1), B, T, d, m->s));
-    CK(gemm_wgrad(m, m->stemW, m->last_x, DT_F32, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    if (m->stem_kp && r.M % 64 == 0 && r.M >= 256 && d % 128 == 0 && !g_force_tn_regstage) {
+        DenseW wp = m->stemW; wp.K = m->stem_kp;           // packed rows of the forward pass; only the first F rows of dW exist
+        CK(gemm_wgrad(m, wp, m->W(m->stem_xb), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M, m->F));
+    } else
+        CK(gemm_wgrad(m, m->stemW, m->last_x, DT_F32, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
     return 0;
 }
 
