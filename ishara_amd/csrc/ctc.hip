@@ -39,7 +39,8 @@ DEVI double shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
 template <int NS>
 __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                   int Tn, int C, int L, int blank, float* __restrict__ nll,
-                                                  float* __restrict__ dlogits, float grad_scale, double* __restrict__ ws) {
+                                                  float* __restrict__ dlogits, float grad_scale, double* __restrict__ ws,
+                                                  uint32_t* __restrict__ dlb) {
     constexpr int SP = 64 * NS;
     extern __shared__ float shf[];
     float* lse = shf;                                   // [Tn]
@@ -210,20 +211,28 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                     if (al > -1e29 && bs > -1e29 && logp > -1e29) atomicAdd(&cls[wv][ext[s]], __expf((float)(al + bs - logp)));
                 }
             }
+            float gv = 0.f;
             if (lane < C) {
                 const float sm = expf(lg[(size_t)t * C + lane] - lse[t]);
-                dl[(size_t)t * C + lane] = grad_scale * (sm - cls[wv][lane]);
+                gv = grad_scale * (sm - cls[wv][lane]);
+                dl[(size_t)t * C + lane] = gv;
+            }
+            if (dlb) {      // bf16 copy of the row, zero padded to 128 classes (MFMA operand of the classifier's dgrad / wgrad)
+                const float lo = __shfl(gv, (2 * lane) & 63, 64), hi = __shfl(gv, (2 * lane + 1) & 63, 64);
+                typedef __attribute__((ext_vector_type(2))) __bf16 ctc_bf2;
+                ctc_bf2 pk; pk[0] = (__bf16)(lane < 32 ? lo : 0.f); pk[1] = (__bf16)(lane < 32 ? hi : 0.f);
+                dlb[((size_t)b * Tn + t) * 64 + lane] = __builtin_bit_cast(uint32_t, pk);
             }
         }
     }
 }
 
 int launch_ctc(const float* logits, const int64_t* labels, int B, int T, int C, int L, int blank,
-               float* nll, float* dlogits, float grad_scale, float* ws, hipStream_t s) {
+               float* nll, float* dlogits, float grad_scale, float* ws, hipStream_t s, void* dlb) {
     if (2 * L + 1 > 512 || C > 64) { ishara_set_error("ctc: L=%d (max 255) or C=%d (max 64) unsupported", L, C); return -1; }
     const int ns = ctc_ns(L);
     const size_t shmem = (size_t)T * sizeof(float) + (size_t)64 * ns * sizeof(int);
-#define CTC_L(NS) hipLaunchKernelGGL(ctc_kernel<NS>, dim3(B), dim3(256), shmem, s, logits, labels, T, C, L, blank, nll, dlogits, grad_scale, reinterpret_cast<double*>(ws))
+#define CTC_L(NS) hipLaunchKernelGGL(ctc_kernel<NS>, dim3(B), dim3(256), shmem, s, logits, labels, T, C, L, blank, nll, dlogits, grad_scale, reinterpret_cast<double*>(ws), reinterpret_cast<uint32_t*>(dlb))
     switch (ns) { case 1: CTC_L(1); break; case 2: CTC_L(2); break; case 3: CTC_L(3); break; case 4: CTC_L(4); break;
                   case 5: CTC_L(5); break; case 6: CTC_L(6); break; case 7: CTC_L(7); break; default: CTC_L(8); break; }
 #undef CTC_L

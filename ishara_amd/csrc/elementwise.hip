@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 }
 
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s);
-void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s);
+void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s, int nb = 0, int nbv = 0);
 bool dwconv_bwd_fused_ok(int dt, int C, int k, int padl);
 int launch_dwconv_bwd_fused(int dt, int inop, const void* dy, const void* x, const float* w, void* dx, float* part,
                             int B, int T, int C, int k, int padl, int max_rows, hipStream_t s);

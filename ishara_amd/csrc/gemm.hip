@@ -1397,12 +1397,15 @@ void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_
 // 4-way 83 us, 8-way 106 us per wgrad including the GEMM); 128 slab lanes with one load each ran 10.5 us per 32 MB.
 template <int SL, int CQ>
 __global__ __launch_bounds__(SL * CQ) void reduce_slabs_cols_kernel(const float* __restrict__ slab, float* __restrict__ out0, float* __restrict__ out1,
-                                                                    int n0, int n, int splits, size_t stride) {
+                                                                    int n0, int n, int splits, size_t stride, int nb, int nbv) {
     __shared__ float4 red[SL][CQ];
     const int tid = threadIdx.x, cq = tid % CQ, sl = tid / CQ;
     const int col = blockIdx.x * (CQ * 4) + cq * 4;
+    // nb != 0: the slab rows are nb wide with only the first nbv columns real (zero-padded B operand); out0 rows are nbv wide
+    const int cin = nb ? (col < n0 ? col % nb : col - n0) : 0;
+    const bool valid = col < n && (nb == 0 || cin < nbv);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < n) {
+    if (valid) {
         for (int s0 = sl; s0 < splits; s0 += SL * 8) {
             float4 v[8];
 #pragma unroll
@@ -1416,18 +1419,18 @@ __global__ __launch_bounds__(SL * CQ) void reduce_slabs_cols_kernel(const float*
     }
     red[sl][cq] = acc;
     __syncthreads();
-    if (sl == 0 && col < n) {
+    if (sl == 0 && valid) {
         float4 t = red[0][cq];
 #pragma unroll
         for (int w = 1; w < SL; ++w) { t.x += red[w][cq].x; t.y += red[w][cq].y; t.z += red[w][cq].z; t.w += red[w][cq].w; }
-        float* dst = col < n0 ? out0 + col : out1 + (col - n0);      // parameter blocks of the flat gradient are only 4-byte aligned
+        float* dst = col < n0 ? (nb ? out0 + (size_t)(col / nb) * nbv + cin : out0 + col) : out1 + (col - n0);      // parameter blocks of the flat gradient are only 4-byte aligned
         dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;
     }
 }
-static void launch_reduce_cols(const float* slab, float* out0, float* out1, int n0, int n, int splits, size_t stride, hipStream_t s) {
-    if (n <= 2048) hipLaunchKernelGGL((reduce_slabs_cols_kernel<64, 4>), dim3((n + 15) / 16), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride);   // narrow, many partial rows (LayerNorm, dwconv)
-    else if (splits <= 64) hipLaunchKernelGGL((reduce_slabs_cols_kernel<8, 32>), dim3((n + 127) / 128), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride);
-    else hipLaunchKernelGGL((reduce_slabs_cols_kernel<16, 16>), dim3((n + 63) / 64), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride);
+static void launch_reduce_cols(const float* slab, float* out0, float* out1, int n0, int n, int splits, size_t stride, hipStream_t s, int nb = 0, int nbv = 0) {
+    if (n <= 2048) hipLaunchKernelGGL((reduce_slabs_cols_kernel<64, 4>), dim3((n + 15) / 16), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride, nb, nbv);   // narrow, many partial rows (LayerNorm, dwconv)
+    else if (splits <= 64) hipLaunchKernelGGL((reduce_slabs_cols_kernel<8, 32>), dim3((n + 127) / 128), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride, nb, nbv);
+    else hipLaunchKernelGGL((reduce_slabs_cols_kernel<16, 16>), dim3((n + 63) / 64), dim3(256), 0, s, slab, out0, out1, n0, n, splits, stride, nb, nbv);
 }
 
 static bool reduce_cols_ok(const float* slab, const float* out0, const float* out1, int n0, int n, size_t stride) {
@@ -1436,8 +1439,8 @@ static bool reduce_cols_ok(const float* slab, const float* out0, const float* ou
 }
 
 // out0[0..n0) += column sums of slab[:, 0..n0), out1[0..n1) += column sums of slab[:, n0..n0+n1)   (slab rows `stride` floats apart)
-void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s) {
-    if (reduce_cols_ok(slab, out0, out1, n0, n0 + n1, stride)) { launch_reduce_cols(slab, out0, out1, n0, n0 + n1, splits, stride, s); return; }
+void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s, int nb, int nbv) {
+    if (reduce_cols_ok(slab, out0, out1, n0, n0 + n1, stride)) { launch_reduce_cols(slab, out0, out1, n0, n0 + n1, splits, stride, s, nb, nbv); return; }
     launch_reduce_slabs(slab, out0, n0, splits, stride, s);
     if (out1 && n1 > 0) launch_reduce_slabs(slab + n0, out1, n1, splits, stride, s);
 }
@@ -1473,7 +1476,7 @@ int g_force_tn_regstage = 0;   // tests: force the register-transposing TN kerne
 int g_tn_blocks = 0;
 int g_tn_phase = 0;            // 0: GEMM + slab sums; 1: GEMM kernel only; 2: slab sums only (the model profiles the two separately)
 
-static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s, int ka_valid) {
+static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s, int ka_valid, int nb_valid) {
     const int tiles = (Ka / 128) * (Nb / 128);
     // workgroups: one per CU for up to 8 tiles (same kernel time as two per CU, half the slab bytes: the slab sums go
     // 9.6 -> 7.3 us), two per CU for 12+ tiles (N = 768: 61 vs 72 us); g_tn_blocks != 0 overrides (tools/tn_ablate.py)
@@ -1493,7 +1496,7 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
         else hipLaunchKernelGGL(gemm_tn_tr_kernel<0>, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0);
     }
     if (g_tn_phase != 1)
-        launch_reduce_slabs2(slab, out, ka_valid * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s);   // rows >= ka_valid of A are zero padding (no bias then)
+        launch_reduce_slabs2(slab, out, ka_valid * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s, nb_valid ? Nb : 0, nb_valid);   // rows >= ka_valid of A / columns >= nb_valid of B are zero padding
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1518,9 +1521,11 @@ static int run_tn(int opA, int opB, const void* A, const void* B, float* out, fl
 
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
-                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid) {
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid, int nb_valid) {
     if (M <= 0 || Ka <= 0 || Nb <= 0) { ishara_set_error("gemm_tn: bad shape"); return -1; }
     if (ka_valid <= 0) ka_valid = Ka;
+    if (nb_valid >= Nb || nb_valid < 0) nb_valid = 0;
+    if (nb_valid % 4 != 0) { ishara_set_error("gemm_tn: nb_valid %d must be a multiple of 4", nb_valid); return -1; }
     if ((dtA == DT_BF16 && Ka % 8 != 0) || (dtA == DT_F32 && Ka % 4 != 0) || (dtB == DT_BF16 && Nb % 8 != 0) || (dtB == DT_F32 && Nb % 4 != 0) ||
         ((uintptr_t)A) % 16 != 0 || ((uintptr_t)B) % 16 != 0) {
         ishara_set_error("gemm_tn: operand rows must be 16-byte aligned (Ka=%d Nb=%d)", Ka, Nb); return -1;
@@ -1530,9 +1535,9 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
         M >= 256 && !g_force_tn_regstage)
     {
         if (ka_valid < Ka && dbias) { ishara_set_error("gemm_tn: padded A columns with a bias gradient"); return -1; }
-        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid);
+        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid, nb_valid);
     }
-    if (ka_valid != Ka) { ishara_set_error("gemm_tn: padded A columns need the bf16 transposed-read kernel (M %% 64, Ka %% 128, Nb %% 128)"); return -1; }
+    if (ka_valid != Ka || nb_valid) { ishara_set_error("gemm_tn: padded A columns need the bf16 transposed-read kernel (M %% 64, Ka %% 128, Nb %% 128)"); return -1; }
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<bf16, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
     if (dtA == DT_F32 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<float, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);
     if (dtA == DT_BF16 && dtB == DT_F32 && dtM == DT_BF16) return run_tn<bf16, float, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);

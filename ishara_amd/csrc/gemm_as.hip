@@ -356,8 +356,9 @@ static int as_mask_of(const EpiArgs& ea) {
 }
 
 // the instantiation run_as picks for a feature mask (bf16 C: the listed combinations, else AS_ALL; f32 C: 0 or AS_ALL)
-static int as_inst_mask(bool c_bf16, int mask) {
+static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
     if (!c_bf16) return mask == 0 ? 0 : AS_ALL;
+    if (K == 128) return (mask == AS_DACT || mask == (AS_DACT | AS_DROP)) ? mask : AS_ALL;      // K = 128: the classifier's dgrad only
     switch (mask) {
         case 0: case AS_RESID: case AS_RESID | AS_ROWSCALE: case AS_RESID | AS_DROP: case AS_ACT | AS_PREOUT: case AS_ACT | AS_PREOUT | AS_DROP:
         case AS_ACT | AS_DROP: case AS_ACT: case AS_DACT: case AS_DACT | AS_DROP: case AS_QKV: case AS_ADDTAB: return mask;
@@ -371,7 +372,9 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     constexpr int BR = KT <= 8 ? 128 : 192;      // rows per workgroup
     const dim3 grid((M + BR - 1) / BR), block(256);
     const int mask = as_mask_of(ea);
-    if constexpr (is_bf16_t<TC>::value) {
+    if constexpr (KT == 4) {
+        if (mask == AS_DACT) AS_LAUNCH(AS_DACT); else if (mask == (AS_DACT | AS_DROP)) AS_LAUNCH(AS_DACT | AS_DROP); else AS_LAUNCH(AS_ALL);
+    } else if constexpr (is_bf16_t<TC>::value) {
         // the feature combinations the encoder's forward / backward passes use (model.hip), compiled without the others
         switch (mask) {
             case 0:
@@ -399,8 +402,7 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
 #undef AS_LAUNCH
 
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
-    (void)dtC;
-    if (K != 256 && K != 512) return false;
+    if (K != 256 && K != 512 && !(K == 128 && dtC == DT_BF16)) return false;
     if (N % AS_NS != 0 || N > AS_MAXN || ldb < K || ldb % 8 != 0 || M < 1) return false;
     if (ea.mode == EPI_QKV && (ea.dh % 8 != 0 || ea.T % 8 != 0)) return false;
     return true;
@@ -409,7 +411,7 @@ bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs&
 // profiler key = the rocprof kernel name of the instantiation launch_gemm_nt_as runs
 const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea) {
     static std::map<int, std::string> names;
-    const int inst = as_inst_mask(dtC == DT_BF16, as_mask_of(ea));
+    const int inst = as_inst_mask(dtC == DT_BF16, as_mask_of(ea), K);
     const int id = (dtC == DT_BF16 ? 0 : 1 << 20) | (K << 8) | inst;
     auto it = names.find(id);
     if (it == names.end()) {
@@ -423,6 +425,6 @@ const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea) {
 // returns 1 when the shape is not one this kernel takes (caller falls through to the tile kernels)
 int launch_gemm_nt_as(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s) {
     if (!gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return 1;
-    if (dtC == DT_BF16) return K == 256 ? run_as<bf16, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<bf16, 16>(A, Bt, C, M, N, ldb, ea, s);
+    if (dtC == DT_BF16) return K == 128 ? run_as<bf16, 4>(A, Bt, C, M, N, ldb, ea, s) : (K == 256 ? run_as<bf16, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<bf16, 16>(A, Bt, C, M, N, ldb, ea, s));
     return K == 256 ? run_as<float, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<float, 16>(A, Bt, C, M, N, ldb, ea, s);
 }

@@ -50,7 +50,7 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
 size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM);
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
-                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0);   // ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0, int nb_valid = 0);   // ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
 // xb[M, Kp] (bf16) = x[M, F] (f32), zero padded to Kp columns (F % 4 == 0, Kp % 8 == 0)
 int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s);
 
@@ -143,7 +143,7 @@ int launch_attn_bwd(int dt, const void* q, const void* k, const void* vt, const 
 size_t ctc_workspace_floats(int B, int T, int L);
 // logits [B,T,C] f32; labels [B,L] int64 (padded with blank); nll [B]; dlogits = grad_scale * d nll_b / d logits
 int launch_ctc(const float* logits, const int64_t* labels, int B, int T, int C, int L, int blank,
-               float* nll, float* dlogits, float grad_scale, float* ws, hipStream_t s);
+               float* nll, float* dlogits, float grad_scale, float* ws, hipStream_t s, void* dlb = nullptr);
 int launch_fill_u32(void* p, size_t n_words, uint32_t v, hipStream_t s);   // model.hip
 int launch_mean(const float* v, float* out, int n, float scale, hipStream_t s);
 int launch_greedy_decode(const float* logits, int B, int T, int C, int blank, int* out_idx, int* out_len, hipStream_t s);

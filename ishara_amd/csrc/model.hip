@@ -142,6 +142,7 @@ struct ishara_model {
     int64_t n_total = 0, n_train = 0;
     // graph
     DenseW stemW; BNp stem_bn;
+    int cls_pad = 0; Buf dlb;          // bf16 model: dlogits also as bf16 [M, cls_pad] (zero padded), 0 = f32 operand path
     int stem_kp = 0; Buf stem_xb;      // bf16 model: input rows packed to bf16 [M, stem_kp] (zero padded), 0 = f32-A GEMM path
     Buf stem_h0, stem_out, stem_ssum, stem_ssq, stem_mean, stem_rstd, stem_a, stem_bsh, pe;
     std::vector<ConvBlock> convs;
@@ -305,13 +306,14 @@ static void build_graph(ishara_model* m) {
     m->n_total = off;
 }
 
-static void plan_shadow(ishara_model* m, DenseW& w, int min_ldt = 0) {
+static void plan_shadow(ishara_model* m, DenseW& w, int min_ldt = 0, int min_ldn = 0) {
     const int bk = m->dt == DT_BF16 ? 64 : 32;
     const size_t es = dt_size(m->dt);
     w.ldt = (int)rup(w.K, bk);
     if (w.ldt < min_ldt) w.ldt = min_ldt;      // zero-padded K (the shadow arena is zero-filled, the builder writes k < K)
     w.wt = m->alloc(rup(w.N, 128) * (size_t)w.ldt * es).off;
     w.ldn = (int)rup(w.N, bk);
+    if (w.ldn < min_ldn) w.ldn = min_ldn;
     w.wn = m->alloc(rup(w.K, 128) * (size_t)w.ldn * es).off;
     m->denses.push_back(&w);
 }
@@ -331,7 +333,9 @@ static void plan_workspace(ishara_model* m) {
     for (auto& sb : m->sqz) { later.insert(later.end(), {&sb.ffn1.Wa, &sb.ffn1.Wb, &sb.mha.Wqkv, &sb.mha.Wp, &sb.conv.Wc1, &sb.conv.Wc3, &sb.ffn2.Wa, &sb.ffn2.Wb}); }
     for (auto& cb : m->conf) { later.insert(later.end(), {&cb.ffn1.Wa, &cb.ffn1.Wb, &cb.mha.Wqkv, &cb.mha.Wp, &cb.conv.Wp1, &cb.conv.Wp2, &cb.ffn2.Wa, &cb.ffn2.Wb}); }
     later.push_back(&m->topW); later.push_back(&m->clsW);
-    for (DenseW* w : later) plan_shadow(m, *w);
+    // classifier: its dY operand is the zero-padded bf16 [M, 128] copy of dlogits (bf16 model, <= 64 classes)
+    m->cls_pad = (m->dt == DT_BF16 && m->C <= 64 && m->C % 4 == 0) ? 128 : 0;
+    for (DenseW* w : later) plan_shadow(m, *w, 0, w == &m->clsW ? m->cls_pad : 0);
     m->shadow_end = m->cur;
     m->shadow_tab_off = m->alloc(m->denses.size() * sizeof(ShadowDesc)).off;
     // ---- stem
@@ -397,6 +401,7 @@ static void plan_workspace(ishara_model* m) {
     m->slab = m->f32(slabf);
     m->ctcws = m->f32(ctc_workspace_floats(B, T, m->L));
     m->dlogits = m->f32(Mx * m->C);
+    if (m->cls_pad) m->dlb = m->alloc(Mx * (size_t)m->cls_pad * 2);
     m->nllb = m->f32(B);
     m->delta = m->f32((size_t)B * m->H * T);
     m->ws_need = m->cur;
@@ -507,13 +512,13 @@ static int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA,
     CKP(m, gemm_nt_kernel_name(dtA, m->dt, m->dt, aop, dY, M, w.K, w.N, w.ldn, ea), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
     return 0;
 }
-static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0) {
+static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0, int nb_valid = 0) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
     // the GEMM kernel and the sums of its split-M slabs are profiled under separate keys (the kernel's key is its rocprof name)
     g_tn_phase = 1;
-    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid));
+    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid));
     g_tn_phase = 2;
-    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid));
+    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid));
     g_tn_phase = 0;
     return 0;
 }
@@ -751,7 +756,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
     OpArgs no; EpiArgs e0;
     float* nl = nll ? nll : m->Wf(m->nllb);
     HIP_CHECK_RET(hipMemsetAsync(m->grads, 0, (size_t)m->n_train * sizeof(float), m->s));
-    CKP(m, "ctc", 2.0 * r.M * m->C * 4, 0, launch_ctc(logits, labels, B, T, m->C, m->L, m->C - 1, nl, m->Wf(m->dlogits), loss_scale / (float)B, m->Wf(m->ctcws), m->s));
+    CKP(m, "ctc", 2.0 * r.M * m->C * 4, 0, launch_ctc(logits, labels, B, T, m->C, m->L, m->C - 1, nl, m->Wf(m->dlogits), loss_scale / (float)B, m->Wf(m->ctcws), m->s, m->cls_pad ? m->W(m->dlb) : nullptr));
     if (loss) CKP(m, "mean", 0, 0, launch_mean(nl, loss, B, 1.f / (float)B, m->s));
     // ---- head
     // input of the head = output of the last layer
@@ -761,8 +766,14 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
         hin = L.kind == Layer::CONV ? m->W(m->convs[L.idx].out) : (L.kind == Layer::SQZ ? m->W(m->sqz[L.idx].ffn2.out) : m->W(m->conf[L.idx].ffn2.out));
     }
     EpiArgs eh; eh.drop = dspec(r, m->head_site, m->cfg.head_dropout); eh.dact = DACT_POS; eh.aux = m->W(m->head_hh);
-    CK(gemm_dgrad(m, m->clsW, m->Wf(m->dlogits), DT_F32, m->W(m->t1), r.M, OP_NONE, no, eh));
-    CK(gemm_wgrad(m, m->clsW, m->W(m->head_hh), dt, OP_NONE, no, m->Wf(m->dlogits), DT_F32, OP_NONE, no, r.M));
+    if (m->cls_pad && r.M % 64 == 0 && r.M >= 256 && m->clsW.K % 128 == 0 && !g_force_tn_regstage) {
+        DenseW wp = m->clsW; wp.N = m->cls_pad;          // reduction / output width of the padded operand; the real classes are the first m->C
+        CK(gemm_dgrad(m, wp, m->W(m->dlb), dt, m->W(m->t1), r.M, OP_NONE, no, eh));
+        CK(gemm_wgrad(m, wp, m->W(m->head_hh), dt, OP_NONE, no, m->W(m->dlb), dt, OP_NONE, no, r.M, 0, m->C));
+    } else {
+        CK(gemm_dgrad(m, m->clsW, m->Wf(m->dlogits), DT_F32, m->W(m->t1), r.M, OP_NONE, no, eh));
+        CK(gemm_wgrad(m, m->clsW, m->W(m->head_hh), dt, OP_NONE, no, m->Wf(m->dlogits), DT_F32, OP_NONE, no, r.M));
+    }
     void* g = m->W(m->gA); void* gn = m->W(m->gB);
     CK(gemm_dgrad(m, m->topW, m->W(m->t1), dt, g, r.M, OP_NONE, no, e0));
     CK(gemm_wgrad(m, m->topW, hin, dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));

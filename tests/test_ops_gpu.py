@@ -38,7 +38,7 @@ def close(got, ref, name, rtol, atol):
 # 8 LDS-DMA 64x128; bit0 register-staged; bit1: register-transposing TN
 @pytest.mark.parametrize("regstage", [0, 8192, 8, 1, 3])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0), (3000, 768, 256, 0), (1024, 512, 256, 0), (4096, 128, 128, 0),
+@pytest.mark.parametrize("M,K,N,act", [(300, 276, 64, 0), (256, 64, 128, 1), (1408, 256, 768, 0), (130, 512, 60, 2), (64, 32, 8, 0), (3000, 768, 256, 0), (1024, 512, 256, 0), (4096, 128, 128, 0), (1408, 128, 512, 1),
                                        (1000, 256, 512, 1), (333, 512, 128, 0), (900, 256, 256, 2), (50, 512, 512, 0)])
 def test_dense_fwd_bwd(lib, dt, M, K, N, act, regstage):
     lib.ishara_debug_force_regstage(regstage)
