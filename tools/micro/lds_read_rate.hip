@@ -24,7 +24,7 @@ __global__ __launch_bounds__(512) void k(unsigned* sink, int iters) {
                 const u32x2 v = *reinterpret_cast<const u32x2*>(smem + (base & 0xffff) + lane * 8);
                 acc ^= v.x ^ v.y;
             } else {
-                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + (base & 0xffff) + (lane >> 4) * 256 + (lane & 15) * 8));
+                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + (base & 0xffff) + lane * 8)   /* linear: the four 16-lane row groups 128 B apart (256 B apart would alias the banks 2-way) */);
                 acc ^= (unsigned)v.x ^ ((unsigned)v.w << 16);
             }
         }
