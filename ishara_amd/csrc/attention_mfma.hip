@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
                 if constexpr (DM != 0) {      // 4 consecutive keys: 2 hashes; the keep bits are remembered for the backward kernels
                     const uint32_t kb4 = rng_bits4(rkey, (uint32_t)(key0 + 16 * kt + 4 * g), drop.thr);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p[kt][r] = ((kb4 >> r) & 1u) ? p[kt][r] * drop.scale : 0.f;
+                    for (int r = 0; r < 4; ++r) p[kt][r] = ((kb4 >> r) & 1u) ? p[kt][r] : 0.f;      // the 1/(1-rate) factor is applied once per output below
                     keepbits |= kb4 << (16 * t + 4 * kt);
                 }
             }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
         l += __shfl_xor(l, 32, 64);
         const int qrow = qbase + 16 * t + c;
         if (qrow < Tn) {
-            const float inv = 1.f / l;
+            const float inv = (DM != 0 ? drop.scale : 1.f) / l;
             bf16* orow = o + ((size_t)b * Tn + qrow) * dmodel + h * DH;
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dq_mfma_kernel
                         const bool inb = (!partial) | (key < Tn);                // branchless: exp2(-inf) = 0 for the keys past the end
                         const float xq = fmaf(sacc[kt][t][r], cs, -lsl[t]);
                         const float pv = __builtin_amdgcn_exp2f(inb ? xq : -INFINITY);
-                        ds[kt][r] = pv * (dp[r] - dlt[t]) * scale;
+                        ds[kt][r] = pv * (dp[r] - dlt[t]);                        // * scale once per output (epilogue)
                     }
                 }
 #pragma unroll
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dq_mfma_kernel
             for (int d = 0; d < DT; ++d) {
                 bf16x4 w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = (bf16)acc[d][t][r];
+                for (int r = 0; r < 4; ++r) w[r] = (bf16)(acc[d][t][r] * scale);
                 *reinterpret_cast<bf16x4*>(drow + 16 * d + 4 * g) = w;
             }
         }
@@ -534,10 +534,10 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dkv_mfma_kerne
                             const bool keep = DM == 2 ? ((mw[t][r] >> (16 * hq + 4 * (((kbase + 16 * t) % AF_KC) >> 4) + (c & 3))) & 1u) != 0u
                                                       : rng_keep(Rc[ql], key, drop.thr);
                             dp = keep ? dp * drop.scale : 0.f;
-                            pdv = keep ? pv * drop.scale : 0.f;
+                            pdv = keep ? pv : 0.f;                     // * drop.scale once per dV output (epilogue)
                         }
                         pd[hq][r] = pdv;
-                        ds[hq][r] = pv * (dp - Dlc[ql]) * scale;
+                        ds[hq][r] = pv * (dp - Dlc[ql]);               // * scale once per dK output (epilogue)
                     }
                 pdb[t] = pack8(pd[0], pd[1]);
                 dsb[t] = pack8(ds[0], ds[1]);
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dkv_mfma_kerne
             for (int d = 0; d < DT; ++d) {
                 bf16x4 wk, wv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { wk[r] = (bf16)adk[d][t][r]; wv[r] = (bf16)adv[d][t][r]; }
+                for (int r = 0; r < 4; ++r) { wk[r] = (bf16)(adk[d][t][r] * scale); wv[r] = (bf16)(adv[d][t][r] * (DM != 0 ? drop.scale : 1.f)); }
                 *reinterpret_cast<bf16x4*>(drow + DH + 16 * d + 4 * g) = wk;
                 *reinterpret_cast<bf16x4*>(drow + 2 * DH + 16 * d + 4 * g) = wv;
             }
