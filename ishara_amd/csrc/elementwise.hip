@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(256) void eca_bwd_sample_kernel(const float* __rest
                                                              const float* __restrict__ gn, const float* __restrict__ sg,
                                                              const float* __restrict__ w5, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ E,
-                                                             float* __restrict__ dw5, int C) {
+                                                             float* __restrict__ dw5part, int C) {
     extern __shared__ float sh[];   // dz[C+4], g[C+4]
     float* dz = sh;
     float* g = sh + C + 4;
@@ -1127,16 +1127,23 @@ __global__ __launch_bounds__(256) void eca_bwd_sample_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 5; ++j) { const float v = wave_sum(wp[j]); if (lane == 0) wred[j][wid] = v; }
     __syncthreads();
-    if (threadIdx.x < 5) atomicAdd(dw5 + threadIdx.x, wred[threadIdx.x][0] + wred[threadIdx.x][1] + wred[threadIdx.x][2] + wred[threadIdx.x][3]);
+    if (threadIdx.x < 5) dw5part[(size_t)b * 8 + threadIdx.x] = wred[threadIdx.x][0] + wred[threadIdx.x][1] + wred[threadIdx.x][2] + wred[threadIdx.x][3];   // summed over samples, in order, by the channel kernel
 }
 
 // step 2, per channel (FIN_CL channels x FIN_BL sample lanes per block): dgamma, dbeta, Fc; E[b,c] <- dgn/T - dbeta/Mtot
 __global__ __launch_bounds__(1024) void eca_bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ gap,
                                           const float* __restrict__ sg, const float* __restrict__ mean, const float* __restrict__ rstd,
                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ E, float* __restrict__ Fc,
-                                          int B, int Tn, int C) {
+                                          const float* __restrict__ dw5part, float* __restrict__ dw5, int B, int Tn, int C) {
     __shared__ double rg_[FIN_NW][FIN_CL], rb_[FIN_NW][FIN_CL];
     __shared__ float eb_[FIN_CL];
+    if (blockIdx.x == 0 && threadIdx.x < 5 * 64) {      // ECA tap gradient: per-sample partials of step 1, summed in a fixed order (wave j = tap j)
+        const int j = threadIdx.x >> 6, l = threadIdx.x & 63;
+        float a = 0.f;
+        for (int b = l; b < B; b += 64) a += dw5part[(size_t)b * 8 + j];
+        a = wave_sum(a);
+        if (l == 0) dw5[j] += a;
+    }
     const int cl = threadIdx.x & (FIN_CL - 1), bl = threadIdx.x / FIN_CL, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * FIN_CL + cl;
     const bool act = c < C;
@@ -1169,9 +1176,9 @@ __global__ __launch_bounds__(1024) void eca_bn_bwd_channel_kernel(const float* _
 
 int launch_eca_bn_bwd_finalize(const float* S1, const float* S2, const float* gap, const float* gn, const float* sgate,
                                const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, int B, int T, int C, hipStream_t s) {
-    hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B), dim3(256), 2 * (C + 4) * sizeof(float), s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5, C);
-    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, B, T, C);
+                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part, int B, int T, int C, hipStream_t s) {
+    hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B), dim3(256), 2 * (C + 4) * sizeof(float), s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5part, C);
+    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, dw5part, dw5, B, T, C);
     return LAUNCH_OK();
 }
 
@@ -1285,52 +1292,82 @@ int launch_se_fwd(const float* gap, float invT, const float* W1, const float* b1
     return LAUNCH_OK();
 }
 
+// Squeeze-excite backward, step 1 (one workgroup per sample): dz2 = dse*se*(1-se), dhp = (W2 dz2) * swish'(hid_pre), dgapT = W1 dhp / T;
+// dz2, dhp and h = swish(hid_pre) go to scr[b][C + 2R] for the weight-gradient pass
 __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ dse, const float* __restrict__ gap, float invT,
                                                      const float* __restrict__ W1, const float* __restrict__ W2,
                                                      const float* __restrict__ hid_pre, const float* __restrict__ se,
-                                                     float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
-                                                     float* __restrict__ dgapT, int C, int R) {
-    extern __shared__ float sh[];   // z[C], dp2[C], h[R], dhp[R]
-    float* z = sh;
-    float* dp2 = sh + C;
-    float* h = sh + 2 * C;
-    float* dhp = sh + 2 * C + R;
+                                                     float* __restrict__ scr, float* __restrict__ dgapT, int C, int R) {
+    extern __shared__ float sh[];   // dp2[C], dhp[R]
+    float* dp2 = sh;
+    float* dhp = sh + C;
     const int b = blockIdx.x;
+    float* sb = scr + (size_t)b * (C + 2 * R);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const size_t i = (size_t)b * C + c;
-        z[c] = gap[i] * invT;
         const float sv = se[i];
         const float d = dse[i] * sv * (1.f - sv);
         dp2[c] = d;
-        atomicAdd(db2 + c, d);
+        sb[c] = d;
     }
-    for (int r = threadIdx.x; r < R; r += blockDim.x) h[r] = swishf_(hid_pre[(size_t)b * R + r]);
     __syncthreads();
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
         float acc = 0.f;
         for (int c = 0; c < C; ++c) acc += W2[(size_t)r * C + c] * dp2[c];
-        const float d = acc * dswishf_(hid_pre[(size_t)b * R + r]);
+        const float hp = hid_pre[(size_t)b * R + r];
+        const float d = acc * dswishf_(hp);
         dhp[r] = d;
-        atomicAdd(db1 + r, d);
+        sb[C + r] = d;
+        sb[C + R + r] = swishf_(hp);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C * R; i += blockDim.x) {
-        const int r2 = i / C, c2 = i - r2 * C;          // dW2[r][c] = h[r]*dp2[c]
-        atomicAdd(dW2 + i, h[r2] * dp2[c2]);
-        const int c1 = i / R, r1 = i - c1 * R;          // dW1[c][r] = z[c]*dhp[r]
-        atomicAdd(dW1 + i, z[c1] * dhp[r1]);
-    }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += W1[(size_t)c * R + r] * dhp[r];
         dgapT[(size_t)b * C + c] = acc * invT;
     }
 }
+// step 2: weight gradients as sums over the samples in a fixed order (no float atomics: the gradients repeat bit for bit).
+// workgroup = 64 parameters (lane) x 4 sample groups (wave w takes b = w, w+4, ...; 8 independent loads in flight), combined through LDS:
+// dW1[c][r] += sum_b z[b,c]*dhp[b,r], db1[r] += sum_b dhp[b,r], dW2[r][c] += sum_b h[b,r]*dz2[b,c], db2[c] += sum_b dz2[b,c]
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ scr, const float* __restrict__ gap, float invT,
+                                                       float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                                       int B, int C, int R) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int CR = C * R, S = C + 2 * R;
+    // parameter i -> (first factor pointer / stride, second factor pointer / stride, output)
+    const float* f0 = nullptr; const float* f1 = nullptr; size_t s0 = 0, s1 = S; float sc = 1.f; float* out = nullptr;
+    if (i < CR) { const int r = i / C, c = i - r * C; f0 = scr + C + R + r; s0 = S; f1 = scr + c; out = dW2 + i; }                       // dW2[r][c]: c fastest
+    else if (i < 2 * CR) { const int k = i - CR, c = k / R, r = k - c * R; f0 = gap + c; s0 = C; sc = invT; f1 = scr + C + r; out = dW1 + k; }   // dW1[c][r]
+    else if (i < 2 * CR + C) { f1 = scr + (i - 2 * CR); out = db2 + (i - 2 * CR); }
+    else if (i < 2 * CR + C + R) { f1 = scr + C + (i - 2 * CR - C); out = db1 + (i - 2 * CR - C); }
+    float acc = 0.f;
+    if (out) {
+        for (int b0 = w; b0 < B; b0 += 32) {
+            float a[8], c8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 4 * u;
+                a[u] = (b < B && f0) ? f0[(size_t)b * s0] : 1.f;
+                c8[u] = b < B ? f1[(size_t)b * s1] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += a[u] * sc * c8[u];
+        }
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && out) *out += red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
 
+// scr: B * (C + 2R) floats of scratch
 int launch_se_bwd(const float* dse, const float* gap, float invT, const float* W1, const float* W2,
                   const float* hid_pre, const float* se, float* dW1, float* db1, float* dW2, float* db2,
-                  float* dgapT, int B, int C, int R, hipStream_t s) {
-    hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (2 * C + 2 * R) * sizeof(float), s, dse, gap, invT, W1, W2, hid_pre, se, dW1, db1, dW2, db2, dgapT, C, R);
+                  float* dgapT, float* scr, int B, int C, int R, hipStream_t s) {
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, dse, gap, invT, W1, W2, hid_pre, se, scr, dgapT, C, R);
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3((2 * C * R + C + R + 63) / 64), dim3(256), 0, s, scr, gap, invT, dW1, db1, dW2, db2, B, C, R);
     return LAUNCH_OK();
 }
 

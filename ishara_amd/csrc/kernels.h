@@ -111,7 +111,7 @@ int launch_sample_reduce(int dt, const void* dy, const void* other, const float*
 // Conv1DBlock BN+ECA backward finalize (one block; small)
 int launch_eca_bn_bwd_finalize(const float* S1, const float* S2, const float* gap, const float* gn, const float* sgate,
                                const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, int B, int T, int C, hipStream_t s);
+                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part /* B*8 floats */, int B, int T, int C, hipStream_t s);
 // plain BN backward finalize from per-sample S1,S2: dgamma, dbeta, E[c] = -dbeta/Mtot, Fc = dgamma/Mtot
 int launch_bn_bwd_finalize(const float* S1, const float* S2, float* dgamma, float* dbeta, float* Ecol, float* Fc,
                            int B, int T, int C, hipStream_t s);
@@ -125,7 +125,7 @@ int launch_se_fwd(const float* gap, float invT, const float* W1, const float* b1
 // given dse[b,c] (= sum_t dOut*u3): grads of W1,b1,W2,b2 (atomic) and dgapT[b,c] = dL/dgap * (1/T)
 int launch_se_bwd(const float* dse, const float* gap, float invT, const float* W1, const float* W2,
                   const float* hid_pre, const float* se, float* dW1, float* db1, float* dW2, float* db2,
-                  float* dgapT, int B, int C, int R, hipStream_t s);
+                  float* dgapT, float* scr /* B*(C+2R) floats */, int B, int C, int R, hipStream_t s);
 
 // ---- attention (attention.hip) -----------------------------------------------------
 // q,k [B,H,T,dh], vt [B,H,dh,T]; o [B*T, H*dh]; lse [B,H,T]

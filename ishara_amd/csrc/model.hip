@@ -153,7 +153,7 @@ struct ishara_model {
     uint32_t nsites = 0;
     std::vector<DenseW*> denses;
     // temps
-    Buf gA, gB, t1, t2, t3, S1, S2, E, Fc, Ecol, dse, dgapT, slab, ctcws, dlogits, nllb, delta;
+    Buf gA, gB, t1, t2, t3, S1, S2, E, Fc, Ecol, ecap, dse, dgapT, slab, ctcws, dlogits, nllb, delta;
     size_t shadow_begin = 0, shadow_end = 0;
     size_t shadow_tab_off = 0;             // device descriptor table of the batched shadow build, inside the workspace (no
                                            // hipMalloc/hipFree of our own: a hipFree from a garbage-collected model would break a
@@ -390,7 +390,7 @@ static void plan_workspace(ishara_model* m) {
     m->t1 = m->act(maxw); m->t2 = m->act(maxw); m->t3 = m->act(maxw);
     const int maxc = 2 * d > maxw ? 2 * d : maxw;
     m->S1 = m->f32((size_t)B * maxc); m->S2 = m->f32((size_t)B * maxc); m->E = m->f32((size_t)B * maxc);
-    m->Fc = m->f32(maxc); m->Ecol = m->f32(maxc);
+    m->Fc = m->f32(maxc); m->Ecol = m->f32(maxc); m->ecap = m->f32((size_t)B * 8);
     m->dse = m->f32((size_t)B * d); m->dgapT = m->f32((size_t)B * d);
     size_t slabf = 0;
     for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > slabf) slabf = f; }
@@ -662,7 +662,7 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
     CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
     CKP(m, "eca_bn_bwd_finalize", 0, 0, launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
-                                  m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), B, T, c, m->s));
+                                  m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), m->Wf(m->ecap), B, T, c, m->s));
     CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.sg), m->Wf(m->E), 1, m->Wf(m->Fc), m->W(m->t1), B, T, c, m->s));
     CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s));
     EpiArgs e2; e2.resid = g;
@@ -719,7 +719,7 @@ static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x,
     OpArgs no; EpiArgs e0;
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, g, m->W(c.u3), nullptr, nullptr, m->Wf(m->S1), m->Wf(m->dse), B, T, d, m->s));   // dse = sum_t g*u3
     CKP(m, "se_bwd", 0, 0, launch_se_bwd(m->Wf(m->dse), m->Wf(c.gap), 1.f / T, m->P(c.seW1), m->P(c.seW2), m->Wf(c.hid), m->Wf(c.se),
-                     m->G(c.seW1), m->G(c.seb1), m->G(c.seW2), m->G(c.seb2), m->Wf(m->dgapT), B, d, c.R, m->s));
+                     m->G(c.seW1), m->G(c.seb1), m->G(c.seW2), m->G(c.seb2), m->Wf(m->dgapT), m->Wf(m->E), B, d, c.R, m->s));
     CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, g, m->Wf(c.se), m->Wf(m->dgapT), nullptr, m->W(m->t1), B, T, d, m->s));           // du3
     EpiArgs e1; e1.dact = DACT_SWISH; e1.aux = m->W(c.zd);
     CK(gemm_dgrad(m, c.Wc3, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e1));                                // dzd

@@ -56,17 +56,17 @@ def test_inference_is_per_sample_and_matches_f32(models):
 
 
 def test_training_step_is_deterministic_and_learns(models):
-    """Same seed -> bit-identical logits and loss (the forward pass has no float atomics) and gradients equal to 1e-6 (a
-    few [B,C]-sized backward reductions still use atomics); four steps on one batch lower the CTC loss; the gradients are
-    linear in loss_scale."""
+    """Same seed -> bit-identical logits, loss AND gradients (no global float atomics in either pass: every cross-workgroup
+    sum is a fixed-order reduction of partial rows); four steps on one batch lower the CTC loss; the gradients are linear in
+    loss_scale."""
     mb, _ = models
     x, y = _data(5)
     w0 = mb.get_weights()
     l1, lg1 = mb.loss_and_gradients(x, y, seed=11); g1 = mb.grads.clone(); l1 = float(l1.item()); lg1 = lg1.clone()
     l2, lg2 = mb.loss_and_gradients(x, y, seed=11); g2 = mb.grads.clone(); l2 = float(l2.item())
     assert np.isfinite(l1) and l1 == l2 and torch.equal(lg1, lg2)
-    rel = ((g1 - g2).norm() / g1.norm()).item()
-    assert rel <= 1e-6, f"gradient differs between identical runs: rel-L2 {rel}"
+    ndiff = int((g1 != g2).sum().item())
+    assert ndiff == 0, f"{ndiff} of {g1.numel()} gradient elements differ between identical runs (rel-L2 {((g1 - g2).norm() / g1.norm()).item():.3e})"
     mb.loss_and_gradients(x, y, seed=11, loss_scale=0.5)
     rel = ((mb.grads - 0.5 * g1).norm() / (0.5 * g1).norm()).item()
     assert rel <= 2e-3, f"gradients are not linear in loss_scale: {rel}"
