@@ -575,11 +575,315 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dkv_mfma_kerne
     }
 }
 
+// =====================================================================================
+// Backward in ONE pass (dh = 32, T <= 384): a workgroup of 8 waves owns one (batch, head) and sweeps the queries once.
+// Wave w owns the key tiles {128 j + 16 w .. +15 : j < NT} for the whole kernel: their K / V rows (B operands of S = Q.K^T and
+// dP = dO.V^T) and the dK^T / dV^T accumulators of those keys stay in registers, exactly as in the key-stationary kernel above.
+// What that kernel cannot produce is dQ (a sum over keys, i.e. over waves).  Here every wave also keeps K^T of its keys as A
+// fragments, writes its dS tile (bf16, [own key][32 queries]) to a private LDS tile, reads it back TRANSPOSED
+// (ds_read_b64_tr_b16) as the B operand of dQ^T += K^T.dS^T over its own keys, and the 8 partial dQ^T tiles are summed through
+// LDS in a fixed order.  S, dP and the whole elementwise pass (exp2, dropout, dS) are computed once instead of twice:
+// 5 GEMM units instead of 7 and half the VALU work of the two-kernel backward (the attention backward is VALU bound).
+// delta = rowsum(dO o O) is computed while the dO chunk is staged.
+// =====================================================================================
+#define FB_QLD 40                                   // dS / K tile row stride: 32 columns + 8 pad (80-byte rows)
+#define FB_SMEM (2 * 2 * 64 * 40 * 2 + 3 * 2 * 64 * 4 + 8 * 64 * FB_QLD * 2 + 2 * 8 * 4 * 64 * 16)
+template <int NT, int DM>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
+                                                                const bf16* __restrict__ o, const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                bf16* __restrict__ dqkv, int H, int Tn, float scale, DropSpec drop,
+                                                                const uint32_t* __restrict__ maskbits) {
+    constexpr int DH = 32, DT = 2, KLD = DH + AF_PAD, NP2 = (NT + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char fb_smem[];
+    bf16* Qs = reinterpret_cast<bf16*>(fb_smem);                       // [2][64 * KLD]
+    bf16* Ds = Qs + 2 * 64 * KLD;                                      // [2][64 * KLD]
+    float* Ls = reinterpret_cast<float*>(Ds + 2 * 64 * KLD);           // [2][64]  lse * log2(e)
+    float* Dl = Ls + 128;                                              // [2][64]  delta
+    uint32_t* Rk = reinterpret_cast<uint32_t*>(Dl + 128);              // [2][64]  dropout row keys
+    bf16* dSl = reinterpret_cast<bf16*>(Rk + 128);                     // [8 waves][64 own-key rows * FB_QLD]
+    float* X = reinterpret_cast<float*>(dSl + 8 * 64 * FB_QLD);        // [2 (half parity)][8 waves][4 tiles][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int dmodel = H * DH;
+    const bf16* qb = q + (size_t)bh * Tn * DH;
+    const bf16* kb = k + (size_t)bh * Tn * DH;
+    const bf16* vb = vt + (size_t)bh * DH * Tn;
+    const bf16* dob = dout + (size_t)b * Tn * dmodel + h * DH;
+    const bf16* ob = o + (size_t)b * Tn * dmodel + h * DH;
+    bf16* dSw = dSl + wid * 64 * FB_QLD;
+    const int nqb = (Tn + AF_QB - 1) / AF_QB, nch = (Tn + AF_KC - 1) / AF_KC;
+
+    // ---- K^T fragments of the own keys: stage the rows (local row 16 j + cc = key 128 j + 16 w + cc, zero beyond) in the
+    // private tile and read them transposed; then clear the tile (rows of absent tiles must read as zero dS later).
+    // A wave's LDS operations execute in order, so no barrier is needed around its private tile.
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = lane + 64 * it, L = i >> 2, part = i & 3, j = L >> 4, cc = L & 15;
+        const int key = 128 * j + 16 * wid + cc;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (j < NT && key < Tn) v = *reinterpret_cast<const u32x4*>(kb + (size_t)key * DH + part * 8);
+        *reinterpret_cast<u32x4*>(dSw + L * FB_QLD + part * 8) = v;
+    }
+    asm volatile("" ::: "memory");
+    bf16x8 ktf[DT][NP2];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int p = 0; p < NP2; ++p) ktf[d][p] = trfrag(dSw, FB_QLD, 32 * p + 4 * g, 32 * p + 16 + 4 * g, 16 * d, lane);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = lane + 64 * it;
+        *reinterpret_cast<u32x4*>(dSw + (i >> 2) * FB_QLD + (i & 3) * 8) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // ---- B operands of the own keys: K[key c][dh 8g..], V[key c][dv 8g..]
+    bf16x8 kf[NT], vf[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int key = min(128 * j + 16 * wid + c, Tn - 1);
+        kf[j] = *reinterpret_cast<const bf16x8*>(kb + (size_t)key * DH + 8 * g);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = vb[(size_t)(8 * g + e) * Tn + key];
+        vf[j] = v;
+    }
+    f32x4 adv[DT][NT], adk[DT][NT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { adv[d][j] = f32x4{0.f, 0.f, 0.f, 0.f}; adk[d][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float cs = scale * 1.4426950408889634f;
+
+    // ---- chunk staging: threads 0..255 one 16-byte part of a Q row, threads 256..511 one part of a dO row (+ delta)
+    // (loads only in FB_GLOAD: everything computed from them waits until FB_LSTORE, one chunk later, so that no wait for the
+    // prefetch lands at the top of a chunk)
+    u32x4 rq = u32x4{0u, 0u, 0u, 0u}, ro = u32x4{0u, 0u, 0u, 0u};
+    float rl = 0.f;
+    uint32_t rr = 0;
+#define FB_GLOAD(ch)                                                                                              \
+    {                                                                                                             \
+        const int q0_ = (ch) * AF_KC, pi_ = tid & 255;                                                            \
+        const int row_ = min(q0_ + (pi_ >> 2), Tn - 1), part_ = pi_ & 3;                                          \
+        if (tid < 256) rq = *reinterpret_cast<const u32x4*>(qb + (size_t)row_ * DH + part_ * 8);                  \
+        else {                                                                                                    \
+            rq = *reinterpret_cast<const u32x4*>(dob + (size_t)row_ * dmodel + part_ * 8);                        \
+            ro = *reinterpret_cast<const u32x4*>(ob + (size_t)row_ * dmodel + part_ * 8);                         \
+        }                                                                                                         \
+        const int qr_ = min(q0_ + (tid & 63), Tn - 1);                                                            \
+        if (tid < 64) rl = lse[(size_t)bh * Tn + qr_];                                                            \
+        else if (tid < 128) rr = rng_row_key(drop.key, (uint32_t)(bh * Tn + q0_ + (tid & 63)));                  \
+    }
+#define FB_LSTORE(buf)                                                                                            \
+    {                                                                                                             \
+        const int pi_ = tid & 255;                                                                                \
+        bf16* dst_ = (tid < 256 ? Qs : Ds) + (buf) * 64 * KLD + (pi_ >> 2) * KLD + (pi_ & 3) * 8;                 \
+        asm volatile("" : "+v"(rq), "+v"(ro), "+v"(rl));    /* nothing computed from the prefetch before this point */   \
+        *reinterpret_cast<u32x4*>(dst_) = rq;                                                                     \
+        if (tid >= 256) {            /* delta = rowsum(dO o O): 8 products per part, the 4 parts of a row are adjacent lanes */ \
+            const bf16x8 df_ = __builtin_bit_cast(bf16x8, rq), of_ = __builtin_bit_cast(bf16x8, ro);              \
+            float pd_ = 0.f;                                                                                      \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) pd_ += (float)df_[e] * (float)of_[e];                   \
+            pd_ += __shfl_xor(pd_, 1, 64);                                                                        \
+            pd_ += __shfl_xor(pd_, 2, 64);                                                                        \
+            if ((pi_ & 3) == 0) Dl[(buf) * 64 + (pi_ >> 2)] = pd_;                                                \
+        }                                                                                                         \
+        if (tid < 64) Ls[(buf) * 64 + tid] = rl * 1.4426950408889634f;                                            \
+        else if (tid < 128) Rk[(buf) * 64 + tid - 64] = rr;                                                       \
+    }
+    u32x4 mwn[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        mwn[j] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (DM == 2)
+            mwn[j] = *reinterpret_cast<const u32x4*>(maskbits + ((size_t)(bh * nqb) * nch + min(128 * j + 16 * wid, Tn - 8) / AF_KC) * 256 + (c >> 2) * 16 + 4 * g);
+    }
+    FB_GLOAD(0);
+    FB_LSTORE(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool more = ch + 1 < nch;
+        if (more) FB_GLOAD(ch + 1);
+        const bf16* Qc = Qs + (ch & 1) * 64 * KLD;
+        const bf16* Dc = Ds + (ch & 1) * 64 * KLD;
+        const float* Lc = Ls + (ch & 1) * 64;
+        const float* Dlc = Dl + (ch & 1) * 64;
+        const uint32_t* Rc = Rk + (ch & 1) * 64;
+        const int q0 = ch * AF_KC;
+#pragma unroll 1
+        for (int ks = 0; ks < 2; ++ks) {
+            // ---- per half (32 queries): A fragments of S / dP, transposed dO / Q fragments, row constants
+            bf16x8 qfr[2], dfr[2], dtf[DT], qtf[DT];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                qfr[hq] = *reinterpret_cast<const bf16x8*>(Qc + (16 * (2 * ks + hq) + c) * KLD + 8 * g);
+                dfr[hq] = *reinterpret_cast<const bf16x8*>(Dc + (16 * (2 * ks + hq) + c) * KLD + 8 * g);
+            }
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                dtf[d] = trfrag(Dc, KLD, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
+                qtf[d] = trfrag(Qc, KLD, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, 16 * d, lane);
+            }
+            float nlv[2][4], dlv[2][4];
+            uint32_t rkv[2][4];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = 32 * ks + 16 * hq + 4 * g + r;
+                    const float lraw = Lc[ql];                               // unconditional LDS read + select (a conditional read is an exec-mask branch per element)
+                    nlv[hq][r] = (q0 + ql < Tn) ? -lraw : -INFINITY;         // queries past the end: exp2(-inf) = 0, no per-score select
+                    dlv[hq][r] = Dlc[ql];
+                    rkv[hq][r] = DM == 1 ? Rc[ql] : 0u;
+                }
+            const int qq = q0 + 32 * ks;
+            u32x4 mwv[NT];                                                  // keep bits of the own tiles for THIS half (loaded one half ahead: an L2 / HBM
+#pragma unroll                                                              // round trip is as long as a whole half with only two waves per SIMD)
+            for (int j = 0; j < NT; ++j) mwv[j] = mwn[j];
+            if constexpr (DM == 2) {          // branch-free (clamped indices): a conditional load made hipcc wait for and copy each one on the spot
+                const int qn = min(qq + 32, Tn - 8);                        // next half (the last half re-reads itself)
+                const size_t qbn = (size_t)(bh * nqb + qn / AF_QB) * nch;
+                const int wfn = (qn % AF_QB) >> 5;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    mwn[j] = *reinterpret_cast<const u32x4*>(maskbits + (qbn + min(128 * j + 16 * wid, Tn - 8) / AF_KC) * 256 + wfn * 64 + (c >> 2) * 16 + 4 * g);
+            }
+            f32x4 dq[4];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) dq[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int keyt = 128 * j + 16 * wid;                        // wave-uniform
+                if (keyt < Tn) {
+                    f32x4 sacc[2], dpa[2];
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) {
+                        sacc[hq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[hq], kf[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        dpa[hq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[hq], vf[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    }
+                    const u32x4 mw = mwv[j];
+                    const int sh = 4 * ((keyt % AF_KC) >> 4) + (c & 3);
+                    const uint32_t key = (uint32_t)(keyt + c);
+                    // element (hq, r): query q0 + 32ks + 16hq + 4g + r, key keyt + c
+                    float pd[2][4], ds[2][4];
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[hq][r], cs, nlv[hq][r]));
+                            float dp = dpa[hq][r], pdv = pv;
+                            if constexpr (DM != 0) {
+                                const bool keep = DM == 2 ? ((mw[r] >> (16 * hq + sh)) & 1u) != 0u : rng_keep(rkv[hq][r], key, drop.thr);
+                                dp = keep ? dp * drop.scale : 0.f;
+                                pdv = keep ? pv : 0.f;                       // * drop.scale once per dV output
+                            }
+                            pd[hq][r] = pdv;
+                            ds[hq][r] = pv * (dp - dlv[hq][r]);              // * scale once per dK / dQ output
+                        }
+                    if (keyt + 16 > Tn && (int)key >= Tn) {                  // ragged last key tile (T % 16 == 8): its absent keys contribute nothing
+#pragma unroll
+                        for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { pd[hq][r] = 0.f; ds[hq][r] = 0.f; }
+                    }
+                    const bf16x8 pdb = pack8(pd[0], pd[1]);
+                    const bf16x8 dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        adv[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dtf[d], pdb, adv[d][j], 0, 0, 0);
+                        adk[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[d], dsb, adk[d][j], 0, 0, 0);
+                    }
+                    // dS tile row (own key 16 j + c), queries 16hq + 4g .. +3: the halves of dsb are exactly those two 8-byte pieces
+                    const u32x4 dw = __builtin_bit_cast(u32x4, dsb);
+                    *reinterpret_cast<u32x2*>(dSw + (16 * j + c) * FB_QLD + 4 * g) = u32x2{dw.x, dw.y};
+                    *reinterpret_cast<u32x2*>(dSw + (16 * j + c) * FB_QLD + 16 + 4 * g) = u32x2{dw.z, dw.w};
+                }
+            }
+            // ---- dQ^T (dh x 32 queries) over the own keys, then the fixed-order sum over the 8 waves
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < NP2; ++p)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const bf16x8 bfr = trfrag(dSw, FB_QLD, 32 * p + 4 * g, 32 * p + 16 + 4 * g, 16 * qt, lane);
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) dq[2 * d + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[d][p], bfr, dq[2 * d + qt], 0, 0, 0);
+                }
+            if constexpr (DM == 2) {          // the next half's keep bits have had this whole half to arrive: wait for them HERE, in front of this
+#pragma unroll                                // half's dQ store, or the wait at the top of the next half would also sit out that store's round trip
+                for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(mwn[j]));
+            }
+            float* Xh = X + ks * (8 * 4 * 64 * 4);                          // two halves per chunk: the parity of the half picks the buffer
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) *reinterpret_cast<f32x4*>(Xh + ((wid * 4 + t4) * 64 + lane) * 4) = dq[t4];
+            if (ks == 1 && more) FB_LSTORE((ch + 1) & 1);
+            __syncthreads();                                                // the ONE barrier of a half: partial dQ tiles (and the next chunk) visible;
+            if (tid < 256) {                                                // waves 4..7 run ahead into the next half while waves 0..3 sum this one
+                const int t4 = tid >> 6, d = t4 >> 1, qt = t4 & 1;
+                f32x4 a = *reinterpret_cast<const f32x4*>(Xh + (t4 * 64 + lane) * 4);
+#pragma unroll
+                for (int wv = 1; wv < 8; ++wv) a += *reinterpret_cast<const f32x4*>(Xh + ((wv * 4 + t4) * 64 + lane) * 4);
+                const int qrow = qq + 16 * qt + c;
+                if (qrow < Tn) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r] = (bf16)(a[r] * scale);
+                    *reinterpret_cast<bf16x4*>(dqkv + ((size_t)b * Tn + qrow) * (3 * dmodel) + h * 3 * DH + 16 * d + 4 * g) = w;
+                }
+            }
+        }
+    }
+#undef FB_GLOAD
+#undef FB_LSTORE
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int key = 128 * j + 16 * wid + c;
+        if (key < Tn) {
+            bf16* drow = dqkv + ((size_t)b * Tn + key) * (3 * dmodel) + h * 3 * DH;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                bf16x4 wk, wv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { wk[r] = (bf16)(adk[d][j][r] * scale); wv[r] = (bf16)(adv[d][j][r] * (DM != 0 ? drop.scale : 1.f)); }
+                *reinterpret_cast<bf16x4*>(drow + DH + 16 * d + 4 * g) = wk;
+                *reinterpret_cast<bf16x4*>(drow + 2 * DH + 16 * d + 4 * g) = wv;
+            }
+        }
+    }
+}
+
+int g_attn_bwd_two_pass = 0;     // tests / tools: 1 forces the two-kernel backward
+
+template <int NT, int DM>
+static int launch_fused_bwd(const void* q, const void* k, const void* vt, const void* o, const void* dout, const float* lse, void* dqkv,
+                            int B, int H, int T, float scale, DropSpec drop, const uint32_t* maskbits, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NT, DM>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
+            ishara_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS", (int)FB_SMEM); return -2;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, DM>), dim3(B * H), dim3(512), FB_SMEM, s, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)o,
+                       (const bf16*)dout, lse, (bf16*)dqkv, H, T, scale, drop, maskbits);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_attn_bwd_mfma(const void* q, const void* k, const void* vt, const void* o, const void* dout, const float* lse,
                          float* delta, void* dqkv, int B, int H, int T, int dh, float scale, DropSpec drop, uint32_t* maskbits, hipStream_t s) {
     if (T % 8 != 0) { ishara_set_error("attn_bwd_mfma: T %% 8 != 0"); return -1; }
     dim3 grid(((T + AF_QB - 1) / AF_QB) * B * H);
     const int dm = drop.thr == 0 ? 0 : (maskbits ? 2 : 1);      // measured per layer (B256 H8 T384 dh32): hash fwd 155 + bwd 452 us, cached bits 168 + 361 us
+    if (dh == 32 && T <= 384 && !g_attn_bwd_two_pass) {          // one-pass backward: S, dP and the elementwise pass computed once
+        const int nt = (T + 127) / 128;
+#define FB_DM(NTT) (dm == 0 ? launch_fused_bwd<NTT, 0>(q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s) \
+                  : dm == 1 ? launch_fused_bwd<NTT, 1>(q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s) \
+                            : launch_fused_bwd<NTT, 2>(q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s))
+        return nt == 1 ? FB_DM(1) : (nt == 2 ? FB_DM(2) : FB_DM(3));
+#undef FB_DM
+    }
 #define ATT_BWD(DHH, DMM)                                                                                                                    \
     do {                                                                                                                                     \
         hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DHH, DMM>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)o, \

@@ -200,7 +200,7 @@ def _attn_ref(qkv, B, H, T, dh, scale, mask):
 @pytest.mark.parametrize("impl", [0, 1])   # 0 lane-split VALU kernels, 1 MFMA flash kernels (bf16, dh 32/64)
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("B,H,T,dh,rate", [(2, 8, 176, 8, 0.0), (2, 4, 64, 32, 0.2), (1, 2, 384, 64, 0.1), (3, 8, 16, 16, 0.0),
-                                           (2, 3, 176, 32, 0.2), (1, 2, 512, 64, 0.0), (2, 2, 384, 32, 0.0)])
+                                           (2, 3, 176, 32, 0.2), (1, 2, 512, 64, 0.0), (2, 2, 384, 32, 0.0), (2, 4, 200, 32, 0.1), (1, 8, 384, 32, 0.1)])
 def test_attention(lib, dt, B, H, T, dh, rate, impl):
     if impl == 1 and (dt != "bf16" or dh not in (32, 64)):
         pytest.skip("MFMA attention: bf16, head dim 32/64")
