@@ -587,21 +587,24 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dkv_mfma_kerne
 // delta = rowsum(dO o O) is computed while the dO chunk is staged.
 // =====================================================================================
 #define FB_QLD 40                                   // dS / K tile row stride: 32 columns + 8 pad (80-byte rows)
-#define FB_SMEM (2 * 2 * 64 * 40 * 2 + 3 * 2 * 64 * 4 + 8 * 64 * FB_QLD * 2 + 2 * 8 * 4 * 64 * 16)
-template <int NT, int DM>
-__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
+// LDS: Q / dO chunks (double buffered) + row constants, NW private dS tiles of 32 * NP2 rows, two dQ exchange buffers of NW * 4 KB
+constexpr int fb_smem_bytes(int NW, int NT) { return 2 * 2 * 64 * 40 * 2 + 3 * 2 * 64 * 4 + NW * 32 * ((NT + 1) / 2) * FB_QLD * 2 + 2 * NW * 4 * 64 * 16; }
+// NW waves (8 or 12: two or three per SIMD), NT key tiles per wave: wave w owns the keys 16 NW j + 16 w .. +15, j < NT (T <= 16 NW NT).
+// FULL: T == 16 NW NT (no ragged tile / chunk: the per-tile branches and bounds selects are compiled out)
+template <int NW, int NT, int DM, bool FULL>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_fused_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
                                                                 const bf16* __restrict__ o, const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16* __restrict__ dqkv, int H, int Tn, float scale, DropSpec drop,
                                                                 const uint32_t* __restrict__ maskbits) {
-    constexpr int DH = 32, DT = 2, KLD = DH + AF_PAD, NP2 = (NT + 1) / 2;
+    constexpr int DH = 32, DT = 2, KLD = DH + AF_PAD, NP2 = (NT + 1) / 2, KST = 16 * NW, ROWS = 32 * NP2;
     extern __shared__ __attribute__((aligned(16))) char fb_smem[];
     bf16* Qs = reinterpret_cast<bf16*>(fb_smem);                       // [2][64 * KLD]
     bf16* Ds = Qs + 2 * 64 * KLD;                                      // [2][64 * KLD]
     float* Ls = reinterpret_cast<float*>(Ds + 2 * 64 * KLD);           // [2][64]  lse * log2(e)
     float* Dl = Ls + 128;                                              // [2][64]  delta
     uint32_t* Rk = reinterpret_cast<uint32_t*>(Dl + 128);              // [2][64]  dropout row keys
-    bf16* dSl = reinterpret_cast<bf16*>(Rk + 128);                     // [8 waves][64 own-key rows * FB_QLD]
-    float* X = reinterpret_cast<float*>(dSl + 8 * 64 * FB_QLD);        // [2 (half parity)][8 waves][4 tiles][64 lanes][4]
+    bf16* dSl = reinterpret_cast<bf16*>(Rk + 128);                     // [NW waves][ROWS own-key rows * FB_QLD]
+    float* X = reinterpret_cast<float*>(dSl + NW * ROWS * FB_QLD);     // [2 (half parity)][NW waves][4 tiles][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -612,16 +615,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
     const bf16* vb = vt + (size_t)bh * DH * Tn;
     const bf16* dob = dout + (size_t)b * Tn * dmodel + h * DH;
     const bf16* ob = o + (size_t)b * Tn * dmodel + h * DH;
-    bf16* dSw = dSl + wid * 64 * FB_QLD;
+    bf16* dSw = dSl + wid * ROWS * FB_QLD;
     const int nqb = (Tn + AF_QB - 1) / AF_QB, nch = (Tn + AF_KC - 1) / AF_KC;
 
     // ---- K^T fragments of the own keys: stage the rows (local row 16 j + cc = key 128 j + 16 w + cc, zero beyond) in the
     // private tile and read them transposed; then clear the tile (rows of absent tiles must read as zero dS later).
     // A wave's LDS operations execute in order, so no barrier is needed around its private tile.
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < ROWS / 16; ++it) {
         const int i = lane + 64 * it, L = i >> 2, part = i & 3, j = L >> 4, cc = L & 15;
-        const int key = 128 * j + 16 * wid + cc;
+        const int key = KST * j + 16 * wid + cc;
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
         if (j < NT && key < Tn) v = *reinterpret_cast<const u32x4*>(kb + (size_t)key * DH + part * 8);
         *reinterpret_cast<u32x4*>(dSw + L * FB_QLD + part * 8) = v;
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
         for (int p = 0; p < NP2; ++p) ktf[d][p] = trfrag(dSw, FB_QLD, 32 * p + 4 * g, 32 * p + 16 + 4 * g, 16 * d, lane);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < ROWS / 16; ++it) {
         const int i = lane + 64 * it;
         *reinterpret_cast<u32x4*>(dSw + (i >> 2) * FB_QLD + (i & 3) * 8) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
     bf16x8 kf[NT], vf[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int key = min(128 * j + 16 * wid + c, Tn - 1);
+        const int key = min(KST * j + 16 * wid + c, Tn - 1);
         kf[j] = *reinterpret_cast<const bf16x8*>(kb + (size_t)key * DH + 8 * g);
         bf16x8 v;
 #pragma unroll
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
         const int q0_ = (ch) * AF_KC, pi_ = tid & 255;                                                            \
         const int row_ = min(q0_ + (pi_ >> 2), Tn - 1), part_ = pi_ & 3;                                          \
         if (tid < 256) rq = *reinterpret_cast<const u32x4*>(qb + (size_t)row_ * DH + part_ * 8);                  \
-        else {                                                                                                    \
+        else if (tid < 512) {                                                                                     \
             rq = *reinterpret_cast<const u32x4*>(dob + (size_t)row_ * dmodel + part_ * 8);                        \
             ro = *reinterpret_cast<const u32x4*>(ob + (size_t)row_ * dmodel + part_ * 8);                         \
         }                                                                                                         \
@@ -681,8 +684,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
         const int pi_ = tid & 255;                                                                                \
         bf16* dst_ = (tid < 256 ? Qs : Ds) + (buf) * 64 * KLD + (pi_ >> 2) * KLD + (pi_ & 3) * 8;                 \
         asm volatile("" : "+v"(rq), "+v"(ro), "+v"(rl));    /* nothing computed from the prefetch before this point */   \
-        *reinterpret_cast<u32x4*>(dst_) = rq;                                                                     \
-        if (tid >= 256) {            /* delta = rowsum(dO o O): 8 products per part, the 4 parts of a row are adjacent lanes */ \
+        if (tid < 512) *reinterpret_cast<u32x4*>(dst_) = rq;                                                      \
+        if (tid >= 256 && tid < 512) {            /* delta = rowsum(dO o O): 8 products per part, the 4 parts of a row are adjacent lanes */ \
             const bf16x8 df_ = __builtin_bit_cast(bf16x8, rq), of_ = __builtin_bit_cast(bf16x8, ro);              \
             float pd_ = 0.f;                                                                                      \
             _Pragma("unroll") for (int e = 0; e < 8; ++e) pd_ += (float)df_[e] * (float)of_[e];                   \
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
     for (int j = 0; j < NT; ++j) {
         mwn[j] = u32x4{0u, 0u, 0u, 0u};
         if constexpr (DM == 2)
-            mwn[j] = *reinterpret_cast<const u32x4*>(maskbits + ((size_t)(bh * nqb) * nch + min(128 * j + 16 * wid, Tn - 8) / AF_KC) * 256 + (c >> 2) * 16 + 4 * g);
+            mwn[j] = *reinterpret_cast<const u32x4*>(maskbits + ((size_t)(bh * nqb) * nch + min(KST * j + 16 * wid, Tn - 8) / AF_KC) * 256 + (c >> 2) * 16 + 4 * g);
     }
     FB_GLOAD(0);
     FB_LSTORE(0);
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
                 for (int r = 0; r < 4; ++r) {
                     const int ql = 32 * ks + 16 * hq + 4 * g + r;
                     const float lraw = Lc[ql];                               // unconditional LDS read + select (a conditional read is an exec-mask branch per element)
-                    nlv[hq][r] = (q0 + ql < Tn) ? -lraw : -INFINITY;         // queries past the end: exp2(-inf) = 0, no per-score select
+                    nlv[hq][r] = (FULL || q0 + ql < Tn) ? -lraw : -INFINITY; // queries past the end: exp2(-inf) = 0, no per-score select
                     dlv[hq][r] = Dlc[ql];
                     rkv[hq][r] = DM == 1 ? Rc[ql] : 0u;
                 }
@@ -748,21 +751,26 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
                 const int wfn = (qn % AF_QB) >> 5;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    mwn[j] = *reinterpret_cast<const u32x4*>(maskbits + (qbn + min(128 * j + 16 * wid, Tn - 8) / AF_KC) * 256 + wfn * 64 + (c >> 2) * 16 + 4 * g);
+                    mwn[j] = *reinterpret_cast<const u32x4*>(maskbits + (qbn + min(KST * j + 16 * wid, Tn - 8) / AF_KC) * 256 + wfn * 64 + (c >> 2) * 16 + 4 * g);
             }
             f32x4 dq[4];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) dq[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // scores and dP of all own tiles first: their MFMA latency hides behind one another instead of in front of every tile's VALU pass
+            f32x4 saccv[NT][2], dpav[NT][2];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    saccv[j][hq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[hq], kf[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dpav[j][hq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[hq], vf[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int keyt = 128 * j + 16 * wid;                        // wave-uniform
-                if (keyt < Tn) {
-                    f32x4 sacc[2], dpa[2];
-#pragma unroll
-                    for (int hq = 0; hq < 2; ++hq) {
-                        sacc[hq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[hq], kf[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                        dpa[hq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[hq], vf[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    }
+                const int keyt = KST * j + 16 * wid;                        // wave-uniform
+                if (FULL || keyt < Tn) {
+                    const f32x4 (&sacc)[2] = saccv[j];
+                    const f32x4 (&dpa)[2] = dpav[j];
                     const u32x4 mw = mwv[j];
                     const int sh = 4 * ((keyt % AF_KC) >> 4) + (c & 3);
                     const uint32_t key = (uint32_t)(keyt + c);
@@ -782,7 +790,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
                             pd[hq][r] = pdv;
                             ds[hq][r] = pv * (dp - dlv[hq][r]);              // * scale once per dK / dQ output
                         }
-                    if (keyt + 16 > Tn && (int)key >= Tn) {                  // ragged last key tile (T % 16 == 8): its absent keys contribute nothing
+                    if (!FULL && keyt + 16 > Tn && (int)key >= Tn) {                  // ragged last key tile (T % 16 == 8): its absent keys contribute nothing
 #pragma unroll
                         for (int hq = 0; hq < 2; ++hq)
 #pragma unroll
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
                     *reinterpret_cast<u32x2*>(dSw + (16 * j + c) * FB_QLD + 16 + 4 * g) = u32x2{dw.z, dw.w};
                 }
             }
-            // ---- dQ^T (dh x 32 queries) over the own keys, then the fixed-order sum over the 8 waves
+            // ---- dQ^T (dh x 32 queries) over the own keys, then the fixed-order sum over the NW waves
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int p = 0; p < NP2; ++p)
@@ -815,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
 #pragma unroll                                // half's dQ store, or the wait at the top of the next half would also sit out that store's round trip
                 for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(mwn[j]));
             }
-            float* Xh = X + ks * (8 * 4 * 64 * 4);                          // two halves per chunk: the parity of the half picks the buffer
+            float* Xh = X + ks * (NW * 4 * 64 * 4);                          // two halves per chunk: the parity of the half picks the buffer
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) *reinterpret_cast<f32x4*>(Xh + ((wid * 4 + t4) * 64 + lane) * 4) = dq[t4];
             if (ks == 1 && more) FB_LSTORE((ch + 1) & 1);
@@ -824,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
                 const int t4 = tid >> 6, d = t4 >> 1, qt = t4 & 1;
                 f32x4 a = *reinterpret_cast<const f32x4*>(Xh + (t4 * 64 + lane) * 4);
 #pragma unroll
-                for (int wv = 1; wv < 8; ++wv) a += *reinterpret_cast<const f32x4*>(Xh + ((wv * 4 + t4) * 64 + lane) * 4);
+                for (int wv = 1; wv < NW; ++wv) a += *reinterpret_cast<const f32x4*>(Xh + ((wv * 4 + t4) * 64 + lane) * 4);
                 const int qrow = qq + 16 * qt + c;
                 if (qrow < Tn) {
                     bf16x4 w;
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
 #undef FB_LSTORE
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int key = 128 * j + 16 * wid + c;
+        const int key = KST * j + 16 * wid + c;
         if (key < Tn) {
             bf16* drow = dqkv + ((size_t)b * Tn + key) * (3 * dmodel) + h * 3 * DH;
 #pragma unroll
@@ -856,19 +864,28 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(const bf16* __re
 
 int g_attn_bwd_two_pass = 0;     // tests / tools: 1 forces the two-kernel backward
 
-template <int NT, int DM>
-static int launch_fused_bwd(const void* q, const void* k, const void* vt, const void* o, const void* dout, const float* lse, void* dqkv,
-                            int B, int H, int T, float scale, DropSpec drop, const uint32_t* maskbits, hipStream_t s) {
+template <int NW, int NT, int DM, bool FULL>
+static int launch_fused_bwd_(const void* q, const void* k, const void* vt, const void* o, const void* dout, const float* lse, void* dqkv,
+                             int B, int H, int T, float scale, DropSpec drop, const uint32_t* maskbits, hipStream_t s) {
+    constexpr int SM = fb_smem_bytes(NW, NT);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NT, DM>), hipFuncAttributeMaxDynamicSharedMemorySize, FB_SMEM) != hipSuccess) {
-            ishara_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS", (int)FB_SMEM); return -2;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<NW, NT, DM, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, SM) != hipSuccess) {
+            ishara_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS", SM); return -2;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NT, DM>), dim3(B * H), dim3(512), FB_SMEM, s, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)o,
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NW, NT, DM, FULL>), dim3(B * H), dim3(NW * 64), SM, s, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (const bf16*)o,
                        (const bf16*)dout, lse, (bf16*)dqkv, H, T, scale, drop, maskbits);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+template <int NW, int NT>
+static int launch_fused_bwd(int dm, const void* q, const void* k, const void* vt, const void* o, const void* dout, const float* lse, void* dqkv,
+                            int B, int H, int T, float scale, DropSpec drop, const uint32_t* maskbits, hipStream_t s) {
+#define FB_GO(DMM) (T == 16 * NW * NT ? launch_fused_bwd_<NW, NT, DMM, true>(q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s) \
+                                      : launch_fused_bwd_<NW, NT, DMM, false>(q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s))
+    return dm == 0 ? FB_GO(0) : (dm == 1 ? FB_GO(1) : FB_GO(2));
+#undef FB_GO
 }
 
 int launch_attn_bwd_mfma(const void* q, const void* k, const void* vt, const void* o, const void* dout, const float* lse,
@@ -877,12 +894,11 @@ int launch_attn_bwd_mfma(const void* q, const void* k, const void* vt, const voi
     dim3 grid(((T + AF_QB - 1) / AF_QB) * B * H);
     const int dm = drop.thr == 0 ? 0 : (maskbits ? 2 : 1);      // measured per layer (B256 H8 T384 dh32): hash fwd 155 + bwd 452 us, cached bits 168 + 361 us
     if (dh == 32 && T <= 384 && !g_attn_bwd_two_pass) {          // one-pass backward: S, dP and the elementwise pass computed once
-        const int nt = (T + 127) / 128;
-#define FB_DM(NTT) (dm == 0 ? launch_fused_bwd<NTT, 0>(q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s) \
-                  : dm == 1 ? launch_fused_bwd<NTT, 1>(q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s) \
-                            : launch_fused_bwd<NTT, 2>(q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s))
-        return nt == 1 ? FB_DM(1) : (nt == 2 ? FB_DM(2) : FB_DM(3));
-#undef FB_DM
+        // (waves, key tiles per wave): 12 waves = 3 per SIMD wherever T allows it with <= 2 tiles
+        if (T <= 128) return launch_fused_bwd<8, 1>(dm, q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s);
+        if (T <= 192) return launch_fused_bwd<12, 1>(dm, q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s);
+        if (T <= 256) return launch_fused_bwd<8, 2>(dm, q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s);
+        return launch_fused_bwd<12, 2>(dm, q, k, vt, o, dout, lse, dqkv, B, H, T, scale, drop, maskbits, s);
     }
 #define ATT_BWD(DHH, DMM)                                                                                                                    \
     do {                                                                                                                                     \
