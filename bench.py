@@ -32,7 +32,7 @@ MODEL_KW = dict(dim=256, num_conv_squeeze_blocks=2, num_conv_conform_blocks=2, k
                 transformer_kernel_size=15, input_shape=(384, 224))
 
 
-def cpu_baseline(batch: int, steps: int = 2):
+def cpu_baseline(batch: int, steps: int = 12):      # ~11 s of CPU work on the 16-core GPU-box share
     """Full train step of the CPU oracle (fp32, torch-CPU, all host cores) on `batch` clips."""
     import numpy as np
     import torch
