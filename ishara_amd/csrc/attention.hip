@@ -5,7 +5,8 @@
 //
 // impl 0 ("lane-split"): exact-fp32 VALU kernels, one query (or key) per group of 4
 // lanes, each lane owning dh/4 of the head dimension; scores never touch HBM
-// (online softmax forward, recompute-from-LSE backward).  Works for f32 and bf16 I/O.
+// (online softmax forward, recompute-from-LSE backward).  Works for f32 and bf16 I/O, head dims 8, 16, 24, 32, 48, 64
+// (24 and 48 — e.g. the reference's d384 / 8-head sibling model — have no MFMA kernel and run here in bf16 mode too).
 #include "kernels.h"
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
@@ -225,9 +226,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
         switch (dh) {                                                                                     \
             case 8: hipLaunchKernelGGL((KERNEL<TT, 2>), grid, dim3(256), 0, s, __VA_ARGS__); break;        \
             case 16: hipLaunchKernelGGL((KERNEL<TT, 4>), grid, dim3(256), 0, s, __VA_ARGS__); break;       \
+            case 24: hipLaunchKernelGGL((KERNEL<TT, 6>), grid, dim3(256), 0, s, __VA_ARGS__); break;       \
             case 32: hipLaunchKernelGGL((KERNEL<TT, 8>), grid, dim3(256), 0, s, __VA_ARGS__); break;       \
+            case 48: hipLaunchKernelGGL((KERNEL<TT, 12>), grid, dim3(256), 0, s, __VA_ARGS__); break;      \
             case 64: hipLaunchKernelGGL((KERNEL<TT, 16>), grid, dim3(256), 0, s, __VA_ARGS__); break;      \
-            default: ishara_set_error("attention: head dim %d unsupported (8,16,32,64)", dh); return -1;  \
+            default: ishara_set_error("attention: head dim %d unsupported (8,16,24,32,48,64)", dh); return -1;  \
         }                                                                                                 \
     } while (0)
 

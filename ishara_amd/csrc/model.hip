@@ -413,7 +413,7 @@ extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     if (c.dim <= 0 || c.dim % 8 != 0 || c.dim > 512) { ishara_set_error("dim=%d unsupported (multiple of 8, <=512)", c.dim); return -1; }
     if (c.num_heads <= 0 || c.dim % c.num_heads != 0) { ishara_set_error("dim %% num_heads != 0"); return -1; }
     const int dh = c.dim / c.num_heads;
-    if (dh != 8 && dh != 16 && dh != 32 && dh != 64) { ishara_set_error("head dim %d unsupported (8,16,32,64)", dh); return -1; }
+    if (dh != 8 && dh != 16 && dh != 24 && dh != 32 && dh != 48 && dh != 64) { ishara_set_error("head dim %d unsupported (8,16,24,32,48,64)", dh); return -1; }
     if (c.frames <= 0 || c.frames % 8 != 0 || c.frames > 512) { ishara_set_error("frames=%d unsupported (multiple of 8, <=512)", c.frames); return -1; }
     if (c.features <= 0 || c.features % 4 != 0) { ishara_set_error("features=%d unsupported (positive multiple of 4: 16-byte input rows)", c.features); return -1; }
     if (c.num_classes < 2 || c.num_classes > 64) { ishara_set_error("num_classes=%d unsupported (2..64)", c.num_classes); return -1; }

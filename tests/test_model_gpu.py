@@ -30,6 +30,9 @@ CFGS = {
     # T not a multiple of 64, d=192 (6 heads of 32: off the K=256/512 GEMM fast path), a single clip per batch
     "ragged": dict(dim=192, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(200, 28), B=1,
                    num_heads=6, kernel_sizes=[11, 3], num_conv_per_block=1),
+    # head dim 48 (the d384 / 8-head sibling model's): no MFMA attention kernel, the lane-split kernels serve it in both modes
+    "dh48": dict(dim=96, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(64, 20), B=2,
+                 num_heads=2, kernel_sizes=[3], num_conv_per_block=1),
 }
 
 
