@@ -209,12 +209,12 @@ enum : int { OUT_NONE = 0, OUT_DSWISH = 1, OUT_DGLU = 2 };
 
 // KC: compile-time tap count (11: the tap loop is fully unrolled, so the 8-row register window slides by renaming
 // instead of 28 v_mov per tap and the tap weights are loaded ahead of use); 0: run-time k
-template <typename T, int KC>
+template <typename T, int KC, int KM>      // KC: unrolled tap count (0 = runtime k); KM: largest k this instantiation takes (sizes the LDS tile: 37 / 40 / 48 KB)
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                      T* __restrict__ y, const T* __restrict__ aux,
                                                      float* __restrict__ ssum, float* __restrict__ ssq,
                                                      int B, int Tn, int C, int k, int padl, int inop, int outop, int flip, float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float tile[(DW_TT + DW_MAXK - 1) * DW_CT];
+    __shared__ __attribute__((aligned(16))) float tile[(DW_TT + KM - 1) * DW_CT];
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
     const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
     // tile are issued before the first use (rows <= 94 -> at most 6 row groups per thread).
     {
         const int ch = c0 + (tid & 15) * 8;
-        constexpr int NIT = (DW_TT + DW_MAXK - 1 + 15) / 16;
+        constexpr int NIT = (DW_TT + KM - 1 + 15) / 16;
         float v[NIT][8], gl[NIT][8];
         bool ok[NIT];
 #pragma unroll
@@ -684,8 +684,9 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restri
 }
 #define DWK_LAUNCH(TT, ...)                                                                                              \
     do {                                                                                                                \
-        if (k == 11) hipLaunchKernelGGL((dwconv_kernel<TT, 11>), grid, dim3(256), 0, s, __VA_ARGS__);   /* 74 -> 65 us */  \
-        else hipLaunchKernelGGL((dwconv_kernel<TT, 0>), grid, dim3(256), 0, s, __VA_ARGS__);            /* K = 15 unrolled: 86 vs 78 us */ \
+        if (k == 11) hipLaunchKernelGGL((dwconv_kernel<TT, 11, 11>), grid, dim3(256), 0, s, __VA_ARGS__);   /* 74 -> 65 us */  \
+        else if (k <= 15) hipLaunchKernelGGL((dwconv_kernel<TT, 0, 15>), grid, dim3(256), 0, s, __VA_ARGS__);   /* K = 15 unrolled: 86 vs 78 us */ \
+        else hipLaunchKernelGGL((dwconv_kernel<TT, 0, DW_MAXK>), grid, dim3(256), 0, s, __VA_ARGS__);            \
     } while (0)
 size_t dwconv_fwd_scratch_floats(int B, int T, int C) { return (size_t)B * ((T + DW_TT - 1) / DW_TT) * 2 * C; }
 
