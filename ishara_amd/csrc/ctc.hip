@@ -78,12 +78,24 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             skip_fw[k] = s + 2 < S && ext[s + 2] != blank && ext[s + 2] != my[k];                     // s -> s+2
         }
         float em[8][NS], emn[8][NS];
-        auto gather = [&](int t0, int dir, float (&dst)[8][NS]) {      // frames t0, t0 + dir, .., t0 + 7 dir
+        // RAW logits of frames t0, t0 + dir, .., t0 + 7 dir (loads only: subtracting lse here made hipcc wait for the loads right
+        // after issuing them -- a full memory round trip on the serial chain every 8 frames)
+        auto gather = [&](int t0, int dir, float (&dst)[8][NS]) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = min(max(t0 + dir * u, 0), Tn - 1);
 #pragma unroll
-                for (int k = 0; k < NS; ++k) dst[u][k] = lg[(size_t)t * C + my[k]] - lse[t];
+                for (int k = 0; k < NS; ++k) dst[u][k] = lg[(size_t)t * C + my[k]];
+            }
+        };
+        // emission log-probabilities of a gathered group, one group later: the loads have landed by then (the empty asm keeps the
+        // subtraction from being scheduled up to the loads)
+        auto settle = [&](int t0, int dir, float (&src)[8][NS], float (&dst)[8][NS]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float ls = lse[min(max(t0 + dir * u, 0), Tn - 1)];
+#pragma unroll
+                for (int k = 0; k < NS; ++k) { asm volatile("" : "+v"(src[u][k])); dst[u][k] = src[u][k] - ls; }
             }
         };
       if (wave == 0) {
@@ -97,7 +109,8 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
         }
         // the emission log-probabilities of frame group g+1 are gathered while group g runs (register double buffer): the
         // serial chain never waits on memory
-        gather(1, 1, em);
+        gather(1, 1, emn);
+        settle(1, 1, emn, em);
         for (int t0 = 1; t0 < Tn; t0 += 8) {
             if (t0 + 8 < Tn) gather(t0 + 8, 1, emn);
 #pragma unroll
@@ -121,10 +134,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                     for (int k = 0; k < NS; ++k) { a[k] = n[k]; Gw[(size_t)t * SP + NS * lane + k] = n[k]; }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int k = 0; k < NS; ++k) em[u][k] = emn[u][k];
+            if (t0 + 8 < Tn) settle(t0 + 8, 1, emn, em);
         }
         // log p(y | x) = logsumexp(alpha[S-1], alpha[S-2]): both live in (at most two) lanes; reduce max then sum over the wave
         double logp;
@@ -150,7 +160,8 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
         double bt[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) bt[k] = CTC_NEG;
-        gather(Tn - 1, -1, em);
+        gather(Tn - 1, -1, emn);
+        settle(Tn - 1, -1, emn, em);
         for (int tb = Tn - 1; tb >= 0; tb -= 8) {
             if (tb - 8 >= 0) gather(tb - 8, -1, emn);
 #pragma unroll
@@ -183,10 +194,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                     }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int k = 0; k < NS; ++k) em[u][k] = emn[u][k];
+            if (tb - 8 >= 0) settle(tb - 8, -1, emn, em);
         }
       }
     }
