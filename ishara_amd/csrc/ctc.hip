@@ -26,9 +26,9 @@ DEVI double shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
 // ---------------------------------------------------------------------------------------------------------------
 // One 256-thread workgroup per sample:
 //   phase 0 (all threads)  lse[t] = logsumexp(logits[t]); extended label sequence
-//   phase 1 (wave 0)       alpha recursion in log space: the S = 2*len+1 states live in REGISTERS, NS consecutive states
-//                          per lane; the s-1 / s-2 neighbours of a lane's first states come from the previous lane by two
-//                          shuffles per frame.  No barrier and no LDS on the dependency chain (the previous kernel
+//   phase 1 (wave 0)       alpha recursion in log space: the S = 2*len+1 states live in REGISTERS, state s = lane + 64 k;
+//                          only the ceil(S/64) occupied k are computed; the s-1 / s-2 neighbours come from the previous
+//                          lanes by two rotations per frame and k.  No barrier and no LDS on the dependency chain (the previous kernel
 //                          spent a workgroup barrier and an L2 round trip per frame: 0.9 ms at T=384); the emission
 //                          log-probabilities are gathered 8 frames ahead of the chain.
 //   phase 1' (wave 1)      beta recursion the same way, CONCURRENTLY with alpha on another SIMD (the two chains are
@@ -67,11 +67,16 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
 
     if (tid < 128) {
         const int wave = tid >> 6;
+        // state s = lane + 64 k (k < NS): a label of up to 31 symbols (S <= 63) occupies k = 0 only, and the recursion skips the
+        // other k (wave-uniform nk) -- a third of the work of NS consecutive states per lane; lattice rows are written as
+        // contiguous 512-byte pieces.  The s-1 / s-2 neighbours come from lanes l-1 / l-2 by a rotation; lanes 0 (and 1) take
+        // them from lanes 63 (and 62) of the previous k.
+        const int nk = (S + 63) >> 6;
         bool act[NS], skip_bw[NS], skip_fw[NS];
         int my[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const int s = NS * lane + k;
+            const int s = lane + 64 * k;
             my[k] = ext[s];
             act[k] = s < S;
             skip_bw[k] = act[k] && s >= 2 && my[k] != blank && my[k] != ext[s - 2];                   // s-2 -> s
@@ -79,13 +84,14 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
         }
         float em[8][NS], emn[8][NS];
         // RAW logits of frames t0, t0 + dir, .., t0 + 7 dir (loads only: subtracting lse here made hipcc wait for the loads right
-        // after issuing them -- a full memory round trip on the serial chain every 8 frames)
+        // after issuing them)
         auto gather = [&](int t0, int dir, float (&dst)[8][NS]) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = min(max(t0 + dir * u, 0), Tn - 1);
 #pragma unroll
-                for (int k = 0; k < NS; ++k) dst[u][k] = lg[(size_t)t * C + my[k]];
+                for (int k = 0; k < NS; ++k)
+                    if (k < nk) dst[u][k] = lg[(size_t)t * C + my[k]];
             }
         };
         // emission log-probabilities of a gathered group, one group later: the loads have landed by then (the empty asm keeps the
@@ -95,7 +101,8 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             for (int u = 0; u < 8; ++u) {
                 const float ls = lse[min(max(t0 + dir * u, 0), Tn - 1)];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) { asm volatile("" : "+v"(src[u][k])); dst[u][k] = src[u][k] - ls; }
+                for (int k = 0; k < NS; ++k)
+                    if (k < nk) { asm volatile("" : "+v"(src[u][k])); dst[u][k] = src[u][k] - ls; }
             }
         };
       if (wave == 0) {
@@ -103,12 +110,10 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
         double a[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            const int s = NS * lane + k;
+            const int s = lane + 64 * k;
             a[k] = (act[k] && (s == 0 || (s == 1 && len > 0))) ? (double)(lg[my[k]] - lse[0]) : CTC_NEG;
-            Gw[s] = a[k];
+            if (k < nk) Gw[s] = a[k];
         }
-        // the emission log-probabilities of frame group g+1 are gathered while group g runs (register double buffer): the
-        // serial chain never waits on memory
         gather(1, 1, emn);
         settle(1, 1, emn, em);
         for (int t0 = 1; t0 < Tn; t0 += 8) {
@@ -117,21 +122,22 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             for (int u = 0; u < 8; ++u) {
                 const int t = t0 + u;
                 if (t < Tn) {
-                    double up1 = shfl_up_d(a[NS - 1], 1);
-                    double up2 = NS >= 2 ? shfl_up_d(a[NS >= 2 ? NS - 2 : 0], 1) : shfl_up_d(a[0], 2);
-                    if (lane == 0) { up1 = CTC_NEG; up2 = CTC_NEG; }
-                    if (NS == 1 && lane == 1) up2 = CTC_NEG;
-                    double n[NS];
+                    double r1[NS], r2[NS], n[NS];
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        const double a1 = k >= 1 ? a[k - 1] : up1;
-                        const double a2 = k >= 2 ? a[k - 2] : (k == 1 ? up1 : up2);
-                        double v = act[k] ? lse3(a[k], a1, skip_bw[k] ? a2 : CTC_NEG) : CTC_NEG;
-                        if (v > -1e29) v += (double)em[u][k];
-                        n[k] = v;
-                    }
+                    for (int k = 0; k < NS; ++k)
+                        if (k < nk) { r1[k] = __shfl(a[k], (lane + 63) & 63, 64); r2[k] = __shfl(a[k], (lane + 62) & 63, 64); }
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) { a[k] = n[k]; Gw[(size_t)t * SP + NS * lane + k] = n[k]; }
+                    for (int k = 0; k < NS; ++k)
+                        if (k < nk) {
+                            const double a1 = lane >= 1 ? r1[k] : (k >= 1 ? r1[k >= 1 ? k - 1 : 0] : CTC_NEG);
+                            const double a2 = lane >= 2 ? r2[k] : (k >= 1 ? r2[k >= 1 ? k - 1 : 0] : CTC_NEG);
+                            double v = act[k] ? lse3(a[k], a1, skip_bw[k] ? a2 : CTC_NEG) : CTC_NEG;
+                            if (v > -1e29) v += (double)em[u][k];
+                            n[k] = v;
+                        }
+#pragma unroll
+                    for (int k = 0; k < NS; ++k)
+                        if (k < nk) { a[k] = n[k]; Gw[(size_t)t * SP + lane + 64 * k] = n[k]; }
                 }
             }
             if (t0 + 8 < Tn) settle(t0 + 8, 1, emn, em);
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             double cand = CTC_NEG, cand2 = CTC_NEG;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                const int s = NS * lane + k;
+                const int s = lane + 64 * k;
                 if (s == S - 1) cand = a[k];
                 if (s == S - 2 && len > 0) cand2 = a[k];
             }
@@ -172,26 +178,30 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                     if (t == Tn - 1) {
 #pragma unroll
                         for (int k = 0; k < NS; ++k) {
-                            const int s = NS * lane + k;
+                            const int s = lane + 64 * k;
                             bsum[k] = (act[k] && (s == S - 1 || (s == S - 2 && len > 0))) ? 0.0 : CTC_NEG;
                         }
                     } else {
-                        double dn1 = shfl_down_d(bt[0], 1);
-                        double dn2 = NS >= 2 ? shfl_down_d(bt[NS >= 2 ? 1 : 0], 1) : shfl_down_d(bt[0], 2);
-                        if (lane == 63) { dn1 = CTC_NEG; dn2 = CTC_NEG; }
-                        if (NS == 1 && lane == 62) dn2 = CTC_NEG;
+                        double d1[NS], d2[NS];
 #pragma unroll
-                        for (int k = 0; k < NS; ++k) {
-                            const double b1 = k + 1 < NS ? bt[k + 1] : dn1;
-                            const double b2 = k + 2 < NS ? bt[k + 2] : (k + 1 < NS ? dn1 : dn2);
-                            bsum[k] = act[k] ? lse3(bt[k], b1, skip_fw[k] ? b2 : CTC_NEG) : CTC_NEG;
+                        for (int k = 0; k < NS; ++k)
+                            if (k < nk) { d1[k] = __shfl(bt[k], (lane + 1) & 63, 64); d2[k] = __shfl(bt[k], (lane + 2) & 63, 64); }
+#pragma unroll
+                        for (int k = 0; k < NS; ++k)
+                            if (k < nk) {
+                                // successors s+1 / s+2: lanes 63 (and 62) take them from lanes 0 (and 1) of the next k (absent: no state)
+                                const bool nx = k + 1 < NS && k + 1 < nk;
+                                const double b1 = lane <= 62 ? d1[k] : (nx ? d1[k + 1 < NS ? k + 1 : k] : CTC_NEG);
+                                const double b2 = lane <= 61 ? d2[k] : (nx ? d2[k + 1 < NS ? k + 1 : k] : CTC_NEG);
+                                bsum[k] = act[k] ? lse3(bt[k], b1, skip_fw[k] ? b2 : CTC_NEG) : CTC_NEG;
+                            }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NS; ++k)
+                        if (k < nk) {
+                            Hw[(size_t)t * SP + lane + 64 * k] = bsum[k];
+                            bt[k] = bsum[k] > -1e29 ? bsum[k] + (double)em[u][k] : CTC_NEG;
                         }
-                    }
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        Hw[(size_t)t * SP + NS * lane + k] = bsum[k];
-                        bt[k] = bsum[k] > -1e29 ? bsum[k] + (double)em[u][k] : CTC_NEG;
-                    }
                 }
             }
             if (tb - 8 >= 0) settle(tb - 8, -1, emn, em);
