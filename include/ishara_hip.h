@@ -84,6 +84,16 @@ int ishara_forward(ishara_model* m, const float* x, int32_t B, float* logits, in
  * loss (device scalar) = mean_b nll_b; gradients of loss*loss_scale fill grads[0,trainable). */
 int ishara_loss_backward(ishara_model* m, const float* logits, const int64_t* labels, int32_t B,
                          float* loss, float* nll, float loss_scale, ishara_stream s);
+/* Gradient buckets for data parallelism (replaces what tf.distribute / nn.DataParallel do inside the reference's
+ * train step: nb4 c1:63-75, integration.py:1058-1060).  The backward pass completes the flat gradient from its end
+ * (head) towards its start (stem); ishara_grad_bucket(i) gives range i in completion order and
+ * ishara_grad_bucket_wait(i, side) makes the caller's side stream wait for it, so that the all-reduce of a finished
+ * range overlaps the rest of the backward pass.  Call ishara_grad_buckets_enable once before the backward passes
+ * whose ranges are waited for. */
+int32_t ishara_grad_buckets(const ishara_model* m);
+int ishara_grad_bucket(const ishara_model* m, int32_t i, int64_t* offset, int64_t* count);
+int ishara_grad_buckets_enable(ishara_model* m);
+int ishara_grad_bucket_wait(ishara_model* m, int32_t i, ishara_stream side);
 /* Lookahead(RectifiedAdam(sma_threshold=4), sync_period=5) apply_gradients — c7:68-69. */
 int ishara_optimizer_step(ishara_model* m, float lr, float weight_decay, ishara_stream s);
 int32_t ishara_optimizer_iterations(const ishara_model* m);

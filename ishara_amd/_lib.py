@@ -41,6 +41,10 @@ SIGNATURES = {
     "ishara_param_entries": (_I32, [_P]),
     "ishara_param_info": (C.c_int, [_P, _I32, C.POINTER(C.c_char_p), C.POINTER(_I32), C.POINTER(_I64 * 2), C.POINTER(_I64), C.POINTER(_I32)]),
     "ishara_workspace_bytes": (_I64, [_P]),
+    "ishara_grad_buckets": (_I32, [_P]),
+    "ishara_grad_bucket": (C.c_int, [_P, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ishara_grad_buckets_enable": (C.c_int, [_P]),
+    "ishara_grad_bucket_wait": (C.c_int, [_P, _I32, _P]),
     "ishara_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64]),
     "ishara_sync_weights": (C.c_int, [_P, _P]),
     "ishara_forward": (C.c_int, [_P, _P, _I32, _P, _I32, _U32, _P]),

@@ -142,6 +142,9 @@ struct ishara_model {
     int64_t n_total = 0, n_train = 0;
     // graph
     DenseW stemW; BNp stem_bn;
+    // gradient buckets for an overlapped all-reduce: ranges of the flat gradient, in the order the backward pass completes them
+    std::vector<int64_t> bucket_lo, bucket_hi; std::vector<int> bucket_after_layer; std::vector<hipEvent_t> bucket_ev;
+    std::vector<size_t> layer_entry_end; size_t stem_entry_end = 0;
     int cls_pad = 0; Buf dlb;          // bf16 model: dlogits also as bf16 [M, cls_pad] (zero padded), 0 = f32 operand path
     int stem_kp = 0; Buf stem_xb;      // bf16 model: input rows packed to bf16 [M, stem_kp] (zero padded), 0 = f32-A GEMM path
     Buf stem_h0, stem_out, stem_ssum, stem_ssq, stem_mean, stem_rstd, stem_a, stem_bsh, pe;
@@ -212,6 +215,7 @@ static void build_conv(ishara_model* m, const std::string& name, int k) {
     cb.site = m->nsites++;
     m->convs.push_back(cb);
     m->layers.push_back({Layer::CONV, (int)m->convs.size() - 1});
+    m->layer_entry_end.push_back(m->entries.size());
 }
 static FFN build_ffn(ishara_model* m, Norm ln, float eps, const std::string& n1, const std::string& n2, int e, bool out_drop) {
     FFN f; f.ln = ln; f.eps = eps;
@@ -237,6 +241,7 @@ static void build_graph(ishara_model* m) {
     const int d = m->d;
     m->stemW = m->dense("stem_conv", m->F, d, false);
     m->stem_bn = m->bnp("stem_bn", d);
+    m->stem_entry_end = m->entries.size();
     auto conv_blocks = [&](const std::string& tag) {
         for (int j = 0; j < c.num_conv_per_block; ++j) {
             const int k = c.kernel_sizes[j % c.num_kernel_sizes];
@@ -269,6 +274,7 @@ static void build_graph(ishara_model* m) {
         sb.ffn2 = build_ffn(m, n3, 1e-6f, n + "/ffn2_dense1", n + "/ffn2_dense2", esq, true);
         m->sqz.push_back(sb);
         m->layers.push_back({Layer::SQZ, (int)m->sqz.size() - 1});
+        m->layer_entry_end.push_back(m->entries.size());
     }
     for (int i = 0; i < c.num_conv_conform_blocks; ++i) {
         conv_blocks("conform_" + std::to_string(i));
@@ -293,6 +299,7 @@ static void build_graph(ishara_model* m) {
         // dropout sites were numbered in build order ffn1, mha, ffn2 == forward order
         m->conf.push_back(cb);
         m->layers.push_back({Layer::CONF, (int)m->conf.size() - 1});
+        m->layer_entry_end.push_back(m->entries.size());
     }
     m->topW = m->dense("top_conv", d, m->dtop, true);
     m->clsW = m->dense("classifier", m->dtop, m->C, true);
@@ -304,6 +311,30 @@ static void build_graph(ishara_model* m) {
     m->n_train = off;
     for (auto& e : m->entries) if (!e.trainable) { e.offset = off; off += e.shape[0] * (e.ndim == 2 ? e.shape[1] : 1); }
     m->n_total = off;
+
+    // ---- gradient buckets.  Trainable parameters sit in creation order (stem, layers, head) and the backward pass runs head ->
+    // layers in reverse -> stem, so the gradient of everything above a layer boundary is final once that layer's backward is
+    // enqueued: up to 4 ranges of about equal size, cut at layer boundaries, each with an event recorded on the compute stream.
+    {
+        const int nl = (int)m->layers.size();
+        auto first_off = [&](size_t e0) -> int64_t {           // offset of the first trainable entry at index >= e0
+            for (size_t i = e0; i < m->entries.size(); ++i) if (m->entries[i].trainable) return m->entries[i].offset;
+            return m->n_train;
+        };
+        std::vector<int64_t> lo(nl);                            // first gradient element of layer li
+        for (int li = 0; li < nl; ++li) lo[li] = first_off(li == 0 ? m->stem_entry_end : m->layer_entry_end[li - 1]);
+        const int64_t target = m->n_train / 4 + 1;
+        int64_t hi = m->n_train;
+        m->bucket_after_layer.assign(nl, -1);
+        for (int li = nl - 1; li >= 1 && (int)m->bucket_lo.size() < 3; --li) {
+            if (hi - lo[li] >= target && lo[li] > 0) {          // cut below layer li: bucket = [lo[li], hi)
+                m->bucket_after_layer[li] = (int)m->bucket_lo.size();
+                m->bucket_lo.push_back(lo[li]); m->bucket_hi.push_back(hi);
+                hi = lo[li];
+            }
+        }
+        m->bucket_lo.push_back(0); m->bucket_hi.push_back(hi);  // the rest (stem included): complete at the end of the backward pass
+    }
 }
 
 static void plan_shadow(ishara_model* m, DenseW& w, int min_ldt = 0, int min_ldn = 0) {
@@ -447,7 +478,10 @@ extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     *out = m;
     return 0;
 }
-extern "C" void ishara_destroy(ishara_model* m) { delete m; }
+extern "C" void ishara_destroy(ishara_model* m) {
+    if (m) for (auto e : m->bucket_ev) (void)hipEventDestroy(e);
+    delete m;
+}
 extern "C" int64_t ishara_param_total(const ishara_model* m) { return m->n_total; }
 extern "C" int64_t ishara_param_trainable(const ishara_model* m) { return m->n_train; }
 extern "C" int32_t ishara_param_entries(const ishara_model* m) { return (int32_t)m->entries.size(); }
@@ -801,6 +835,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
             STEP(ffn_bwd(m, cb.ffn1, r, lin, g, gn));
         }
 #undef STEP
+        if (!m->bucket_ev.empty() && m->bucket_after_layer[li] >= 0) HIP_CHECK_RET(hipEventRecord(m->bucket_ev[m->bucket_after_layer[li]], m->s));
     }
     // ---- stem
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
@@ -811,6 +846,28 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
         CK(gemm_wgrad(m, wp, m->W(m->stem_xb), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M, m->F));
     } else
         CK(gemm_wgrad(m, m->stemW, m->last_x, DT_F32, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    if (!m->bucket_ev.empty()) HIP_CHECK_RET(hipEventRecord(m->bucket_ev.back(), m->s));
+    return 0;
+}
+
+// ---- gradient buckets (overlapping the data-parallel all-reduce with the backward pass)
+extern "C" int32_t ishara_grad_buckets(const ishara_model* m) { return (int32_t)m->bucket_lo.size(); }
+extern "C" int ishara_grad_bucket(const ishara_model* m, int32_t i, int64_t* offset, int64_t* count) {
+    if (i < 0 || i >= (int32_t)m->bucket_lo.size()) { ishara_set_error("ishara_grad_bucket: index %d outside 0..%d", i, (int)m->bucket_lo.size() - 1); return -1; }
+    *offset = m->bucket_lo[i]; *count = m->bucket_hi[i] - m->bucket_lo[i];
+    return 0;
+}
+// makes `side` wait until bucket i of the LAST ishara_loss_backward is final (events are created on first use)
+extern "C" int ishara_grad_bucket_wait(ishara_model* m, int32_t i, ishara_stream side) {
+    if (i < 0 || i >= (int32_t)m->bucket_lo.size()) { ishara_set_error("ishara_grad_bucket_wait: index %d outside 0..%d", i, (int)m->bucket_lo.size() - 1); return -1; }
+    if (m->bucket_ev.empty()) { ishara_set_error("ishara_grad_bucket_wait: call ishara_grad_buckets_enable before the backward pass"); return -1; }
+    HIP_CHECK_RET(hipStreamWaitEvent((hipStream_t)side, m->bucket_ev[i], 0));
+    return 0;
+}
+extern "C" int ishara_grad_buckets_enable(ishara_model* m) {
+    if (!m->bucket_ev.empty()) return 0;
+    m->bucket_ev.resize(m->bucket_lo.size());
+    for (auto& e : m->bucket_ev) HIP_CHECK_RET(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
 }
 

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, Iterable, List, Optional, Sequence
+from typing import Tuple,  Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -293,11 +293,33 @@ class Model:
         Returns the device loss tensor (no host sync)."""
         from . import parallel
         world = parallel.world_size()
+        overlap = world > 1 and parallel.overlap_enabled()
+        if overlap:
+            self.enable_grad_buckets()
         loss, _ = self.loss_and_gradients(x, y, seed=seed, loss_scale=1.0 / world)
-        if world > 1:
+        if overlap:
+            parallel.allreduce_buckets_(self)          # ranges of the gradient reduced on a side stream as the backward pass finishes them
+        elif world > 1:
             parallel.allreduce_sum_(self.grads[:self.n_train])
         self.apply_gradients()
         return loss
+
+    # ---- gradient buckets (SURVEY 8e: all-reduce overlapped with the backward pass; opt-in, see parallel.overlap_enabled)
+    def grad_buckets(self) -> List[Tuple[int, int]]:
+        """(offset, count) ranges of the flat gradient in the order the backward pass completes them."""
+        out = []
+        for i in range(int(self._lib.ishara_grad_buckets(self._h))):
+            off, cnt = C.c_int64(), C.c_int64()
+            _lib.check(self._lib.ishara_grad_bucket(self._h, i, C.byref(off), C.byref(cnt)), "ishara_grad_bucket")
+            out.append((int(off.value), int(cnt.value)))
+        return out
+
+    def enable_grad_buckets(self):
+        _lib.check(self._lib.ishara_grad_buckets_enable(self._h), "ishara_grad_buckets_enable")
+
+    def wait_grad_bucket(self, i: int, side_stream: "torch.cuda.Stream"):
+        """Makes `side_stream` wait until bucket i of the last backward pass is final (no host sync)."""
+        _lib.check(self._lib.ishara_grad_bucket_wait(self._h, i, C.c_void_p(side_stream.cuda_stream)), "ishara_grad_bucket_wait")
 
     def fit(self, train_dataset: Iterable, validation_data: Optional[Iterable] = None, epochs: int = 1,
             callbacks: Sequence[Callback] = (), steps_per_epoch: Optional[int] = None, verbose: int = 1) -> History:

@@ -55,6 +55,37 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def overlap_enabled() -> bool:
+    """ISHARA_OVERLAP_ALLREDUCE=1: reduce the gradient in buckets on a side stream while the backward pass is still running
+    (allreduce_buckets_).  Off by default: the single flat all-reduce after the backward pass is the path the 1-GPU box can
+    rehearse end to end; the bucketed path is checked against it bit for bit with two gloo ranks (tests/test_bench_gpu.py)."""
+    return os.environ.get("ISHARA_OVERLAP_ALLREDUCE", "0") == "1"
+
+
+_side_streams = {}
+
+
+def allreduce_buckets_(model) -> None:
+    """Sum over ranks of model.grads[:n_train], one collective per gradient bucket.  The backward pass is already enqueued on
+    the current stream when this is called; bucket i's collective is enqueued on a side stream that waits only for the event the
+    library recorded when that range became final, so it runs while the rest of the backward pass executes.  The current
+    stream waits for all of them at the end (before the optimizer step)."""
+    dev = model.grads.device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    works = []
+    for i, (off, cnt) in enumerate(model.grad_buckets()):
+        if cnt <= 0:
+            continue
+        model.wait_grad_bucket(i, side)
+        with torch.cuda.stream(side):
+            works.append(dist.all_reduce(model.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()                                   # current stream <- collective
+    torch.cuda.current_stream(dev).wait_stream(side)
+
+
 def reduce_max(value: float, device=None) -> float:
     """Max over ranks of a host scalar (step-time aggregation in bench.py)."""
     if world_size() == 1:
