@@ -23,4 +23,7 @@ scale = dh ** -0.5
 for rate in (0.0, 0.1):
     f = timeit(lambda: lib.ishara_op_attn_fwd(1, _lib.ptr(qkv), _lib.ptr(o), B, H, T, dh, C.c_float(scale), 7, 3, C.c_float(rate), 1, scp, st()))
     b = timeit(lambda: lib.ishara_op_attn_bwd(1, _lib.ptr(o), _lib.ptr(do), _lib.ptr(dqkv), B, H, T, dh, C.c_float(scale), 7, 3, C.c_float(rate), 1, scp, st()))
-    print(f"rate={rate}: fwd(+qkv split)={f:.0f}us  bwd={b:.0f}us")
+    lib.ishara_debug_force_regstage(1 << 16)          # the two-kernel backward (dq, then dk/dv)
+    b2 = timeit(lambda: lib.ishara_op_attn_bwd(1, _lib.ptr(o), _lib.ptr(do), _lib.ptr(dqkv), B, H, T, dh, C.c_float(scale), 7, 3, C.c_float(rate), 1, scp, st()))
+    lib.ishara_debug_force_regstage(0)
+    print(f"rate={rate}: fwd(+qkv split)={f:.0f}us  bwd one-pass={b:.0f}us  bwd two-pass={b2:.0f}us")
