@@ -10,9 +10,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 if len(sys.argv) > 2:      # debug switches of ishara_debug_force_regstage (e.g. 16384: 256 wgrad workgroups)
     from ishara_amd import _lib
     _lib.load().ishara_debug_force_regstage(int(sys.argv[2]))
-model = get_model(**bench.MODEL_KW, dtype="bf16", max_batch=B, device="cuda:0", seed=0)
+KW, T_, F_ = bench.MODEL_KW, 384, 224
+if len(sys.argv) > 3 and sys.argv[3] == "cfg4":          # BASELINE config #4: d512, 6+6, T512 (not the bench workload; untuned)
+    KW, T_, F_ = dict(dim=512, num_conv_squeeze_blocks=6, num_conv_conform_blocks=6, kernel_sizes=[11, 5, 3], num_conv_per_block=3,
+                      dropout_rate=0.2, num_heads=8, expansion_factor=2, transformer_kernel_size=15, input_shape=(512, 224)), 512, 224
+model = get_model(**KW, dtype="bf16", max_batch=B, device="cuda:0", seed=0)
 g = np.random.default_rng(1)
-x = torch.from_numpy(g.standard_normal((B, 384, 224)).astype(np.float32)).cuda()
+x = torch.from_numpy(g.standard_normal((B, T_, F_)).astype(np.float32)).cuda()
 y = np.full((B, 64), 59, np.int64)
 for b in range(B):
     n = int(g.integers(8, 32)); y[b, :n] = g.integers(0, 59, n)
