@@ -86,7 +86,10 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
     const int c = lane & 15, g = lane >> 4;
     const int mw = m_base + wid * 16 * RT;                   // first row of this wave
     const bool full = m_base + 64 * RT <= M;
-    const int nsteps = N / NS;
+    // blockIdx.y splits the N columns between workgroups when M alone gives too few of them (launcher): this one covers
+    // the column steps [nbase / NS, nbase / NS + nsteps)
+    const int nsteps = N / NS / (int)gridDim.y;
+    const int nbase = (int)blockIdx.y * nsteps * NS;
     const int dmodel = ea.H * ea.dh;
     const bool f_resid = as_on<MASK, AS_RESID>(ea.resid != nullptr), f_dact = as_on<MASK, AS_DACT>(ea.dact != DACT_NONE);
     const bool f_act = as_on<MASK, AS_ACT>(ea.act != ACT_NONE), f_drop = as_on<MASK, AS_DROP>(ea.drop.thr != 0);
@@ -100,7 +103,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
     for (int t = 0; t < DPW; ++t) {
         const int o = (wid * DPW + t) * 1024 + lane * 16;
         const int r = o / RB, p = (o % RB) >> 4;
-        bsrc[t] = Bt + (size_t)r * ldb + ((p ^ as_swz(r)) << 3);
+        bsrc[t] = Bt + (size_t)(nbase + r) * ldb + ((p ^ as_swz(r)) << 3);
     }
     const size_t bstep = (size_t)NS * ldb;
     auto issue = [&](int slot) {
@@ -182,7 +185,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const int n0 = s * NS;
+        const int n0 = nbase + s * NS;
         // ---- T3: residual / act' operand loads of this step (consumed after the MFMA phase), then DMA of stage s+R-1
         // into the slot read in step s-1
         as_u32x4 rs[RT][NG], au[RT][NG];
@@ -370,7 +373,12 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
 template <typename TC, int KT>
 static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea, hipStream_t s) {
     constexpr int BR = KT <= 8 ? 128 : 192;      // rows per workgroup
-    const dim3 grid((M + BR - 1) / BR), block(256);
+    // few rows (config #4 at small batches: M / 192 = 171 workgroups for 512 slots): split the columns 2- or 4-way; every
+    // workgroup then loads its A rows again, which is cheap exactly when M is small
+    const int gx = (M + BR - 1) / BR, slots = KT <= 8 ? 768 : 512;
+    int gy = 1;
+    while (gy < 4 && gx * gy * 2 <= slots && (N / AS_NS) % (gy * 2) == 0 && N / (gy * 2) >= 128) gy *= 2;
+    const dim3 grid(gx, gy), block(256);
     const int mask = as_mask_of(ea);
     if constexpr (KT == 4) {
         if (mask == AS_DACT) AS_LAUNCH(AS_DACT); else if (mask == (AS_DACT | AS_DROP)) AS_LAUNCH(AS_DACT | AS_DROP); else AS_LAUNCH(AS_ALL);
