@@ -20,53 +20,57 @@ N_FACE, N_HAND, N_POSE = 76, 21, 6          # data_loader.py:66-71 (face, left h
 LEFT_START, RIGHT_START = N_FACE, N_FACE + N_HAND
 
 
+_HAND_SWAP = np.arange(N_FACE + 2 * N_HAND + N_POSE)
+_HAND_SWAP[LEFT_START:LEFT_START + N_HAND] = np.arange(RIGHT_START, RIGHT_START + N_HAND)
+_HAND_SWAP[RIGHT_START:RIGHT_START + N_HAND] = np.arange(LEFT_START, LEFT_START + N_HAND)
+
+
+def _resample_time(clip: np.ndarray, length: int) -> np.ndarray:
+    """Nearest-below resample along time: frame j of the result is frame floor(j * (T - 1) / (length - 1))."""
+    return clip[np.linspace(0, clip.shape[0] - 1, length).astype(np.int64)]
+
+
 def apply_augmentations(landmarks: np.ndarray, rng: random.Random) -> np.ndarray:
-    """`ASLDataset._apply_augmentations` (data_loader.py:124-166) with an explicit generator."""
-    # time stretch (nearest-index resample along time)
-    if rng.random() < 0.8:
-        scale = rng.uniform(0.8, 1.2)
-        num_frames = int(landmarks.shape[0] * scale)
-        indices = np.linspace(0, landmarks.shape[0] - 1, num_frames)
-        landmarks = np.stack([landmarks[int(i)] for i in indices])
-    # random shift along time
-    if rng.random() < 0.5:
-        shift = rng.randint(-10, 10)
-        if shift > 0:
-            landmarks = np.pad(landmarks, ((0, shift), (0, 0), (0, 0)))[shift:, :, :]
+    """The four augmentations of `ASLDataset._apply_augmentations` (data_loader.py:124-166) on one clip `[T,124,3]`,
+    drawing from `rng` in the reference's order (gate, then that augmentation's parameters), so a seeded
+    `random.Random` reproduces its output.  Returns a new array; the input is not modified."""
+    clip = np.array(landmarks)
+    if rng.random() < 0.8:                                        # time stretch by 0.8x-1.2x
+        clip = _resample_time(clip, int(clip.shape[0] * rng.uniform(0.8, 1.2)))
+    if rng.random() < 0.5:                                        # shift by up to 10 frames, zero fill
+        s, n = rng.randint(-10, 10), clip.shape[0]
+        moved = np.zeros_like(clip)
+        if s > 0:
+            moved[:max(n - s, 0)] = clip[s:]
+        elif s < 0:
+            moved[-s:] = clip[:max(n + s, 0)]
         else:
-            landmarks = np.pad(landmarks, ((-shift, 0), (0, 0), (0, 0)))[:shift, :, :]      # shift == 0 -> empty, as in the reference
-    # left-right flip
-    if rng.random() < 0.5:
-        temp = landmarks[:, LEFT_START:LEFT_START + N_HAND].copy()
-        landmarks[:, LEFT_START:LEFT_START + N_HAND] = landmarks[:, RIGHT_START:RIGHT_START + N_HAND]
-        landmarks[:, RIGHT_START:RIGHT_START + N_HAND] = temp
-        landmarks[:, :, 0] *= -1
-    # finger dropout
-    if rng.random() < 0.5:
-        num_fingers = rng.randint(2, 6)
-        num_windows = rng.randint(2, 3)
-        for _ in range(num_windows):
-            start_frame = rng.randint(0, landmarks.shape[0] - 10)
-            end_frame = start_frame + rng.randint(5, 10)
-            for _ in range(num_fingers):
-                finger_idx = rng.randint(0, 20)
-                landmarks[start_frame:end_frame, LEFT_START + finger_idx] = 0
-                landmarks[start_frame:end_frame, RIGHT_START + finger_idx] = 0
-    return landmarks
+            moved = moved[:0]                                     # the reference's `[:shift]` with shift == 0 is empty
+        clip = moved
+    if rng.random() < 0.5:                                        # mirror: swap the hands, negate x
+        clip = clip[:, _HAND_SWAP]
+        clip[..., 0] = -clip[..., 0]
+    if rng.random() < 0.5:                                        # finger dropout in 2-3 short windows
+        n_fingers, n_windows = rng.randint(2, 6), rng.randint(2, 3)
+        for _ in range(n_windows):
+            t0 = rng.randint(0, clip.shape[0] - 10)
+            t1 = t0 + rng.randint(5, 10)
+            fingers = np.array([rng.randint(0, 20) for _ in range(n_fingers)])
+            clip[t0:t1, np.concatenate([LEFT_START + fingers, RIGHT_START + fingers])] = 0
+    return clip
 
 
 def pad_resize_normalize(landmarks: np.ndarray, max_frames: int = 384) -> np.ndarray:
-    """data_loader.py:176-188: nearest-index resize down to max_frames or zero-pad up to it, then z-normalise
-    per coordinate over (frames, landmarks)."""
-    num_frames = landmarks.shape[0]
-    if num_frames > max_frames:
-        indices = np.linspace(0, num_frames - 1, max_frames)
-        landmarks = np.stack([landmarks[int(i)] for i in indices])
+    """data_loader.py:176-188: clips longer than `max_frames` are resampled down (nearest-below), shorter ones
+    zero-padded at the end; then each coordinate is z-normalised over (frames, landmarks), eps 1e-8 on the std."""
+    n = landmarks.shape[0]
+    if n > max_frames:
+        clip = _resample_time(landmarks, max_frames).astype(np.float64)
     else:
-        padding = np.zeros((max_frames - num_frames, landmarks.shape[1], landmarks.shape[2]))
-        landmarks = np.concatenate([landmarks, padding], axis=0)
-    landmarks = (landmarks - landmarks.mean(axis=(0, 1), keepdims=True)) / (landmarks.std(axis=(0, 1), keepdims=True) + 1e-8)
-    return landmarks.astype(np.float32)
+        clip = np.zeros((max_frames,) + landmarks.shape[1:], np.float64)
+        clip[:n] = landmarks
+    mu, sd = clip.mean(axis=(0, 1), keepdims=True), clip.std(axis=(0, 1), keepdims=True)
+    return ((clip - mu) / (sd + 1e-8)).astype(np.float32)
 
 
 def to_features(landmarks: np.ndarray, layout: str = "flat") -> np.ndarray:
