@@ -69,12 +69,26 @@ def _relerr(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("name", list(CFGS))
-@pytest.mark.parametrize("dropout", [0.0, 0.2])
-def test_train_step_parity(name, dtype, dropout):
+def _log_observed(rec):
+    """Observed errors go to gpurun_out/parity_observed.jsonl (DESIGN.md §2 quotes them; tolerances are ~2x observed)."""
+    import json
+    path = os.environ.get("ISHARA_PARITY_LOG", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_observed.jsonl"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+# bf16 tolerances by model depth: observed errors grow with the number of chained bf16 activations
+BF16_TOL = dict(logits=0.15, loss=2e-2, grad=0.12, grad_small=0.2, stats=3e-2)
+
+
+def check_train_step(kw, dtype, dropout, tag, bf16_tol=BF16_TOL, check_decode=False):
+    """One training step (forward, CTC, backward) of the HIP library vs the fp64 oracle on the same weights, batch and
+    dropout seed: logits, loss, every parameter gradient, the BatchNorm moving statistics."""
     from oracle import ishara_oracle as O
-    kw = CFGS[name]
     ocfg = _oracle_cfg(kw, dropout)
     model = _build(kw, dtype, dropout)
     W = _perturb(model)
@@ -87,13 +101,7 @@ def test_train_step_parity(name, dtype, dropout):
     W_after = model.get_weights()
     ref_loss, ref_logits, ref_grads, ref_stats = O.loss_and_grads(W, x, y, ocfg, training=True, seed=seed, dtype=torch.float64)
     lerr = float(np.abs(logits - ref_logits).max())
-    if dtype == "f32":
-        assert lerr <= 1e-4, f"logits max-abs-err {lerr:.3e}"
-        assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-4, (loss, ref_loss)
-    else:
-        assert lerr <= 0.15, f"logits max-abs-err {lerr:.3e}"
-        assert abs(loss - ref_loss) <= 2e-2 * abs(ref_loss), (loss, ref_loss)
-    bad = []
+    bad, gmax, gmax_name = [], 0.0, ""
     gscale = max(float(np.abs(v).max()) for v in ref_grads.values())
     for n, rg in ref_grads.items():
         gg = grads[n]
@@ -102,16 +110,44 @@ def test_train_step_parity(name, dtype, dropout):
             if np.abs(gg).max() > (1e-3 if dtype == "f32" else 3e-2) * gscale: bad.append((n, float(np.abs(gg).max() / gscale)))
         elif dtype == "f32":
             e = float(np.abs(gg - rg).max() / np.abs(rg).max())
+            if e > gmax: gmax, gmax_name = e, n
             if e > 1e-3: bad.append((n, e))
         else:
             e = float(np.linalg.norm(gg - rg) / np.linalg.norm(rg))
-            lim = 0.2 if rg.size <= 8 else 0.12      # 5-tap ECA kernels: difference of bf16-rounded sums
+            if rg.size > 8 and e > gmax: gmax, gmax_name = e, n
+            lim = bf16_tol["grad_small"] if rg.size <= 8 else bf16_tol["grad"]      # 5-tap ECA kernels: difference of bf16-rounded sums
             if e > lim: bad.append((n, e))
+    # greedy decode of the training logits against the oracle's, on the frames whose top-2 margin exceeds the logit error
+    dec_same = None
+    if check_decode:
+        top2 = np.sort(ref_logits, axis=2)[:, :, -2:]
+        margin = top2[:, :, 1] - top2[:, :, 0]
+        clear = margin.min(axis=1) > 2 * lerr
+        dec = model.decode_batch(logits_t)
+        dec_same = all(np.array_equal(dec[b], O.decode_phrase(ref_logits[b])) for b in range(kw["B"]) if clear[b])
+    _log_observed(dict(test=tag, dtype=dtype, dropout=dropout, logits_max_abs_err=lerr, loss=loss, ref_loss=ref_loss,
+                       loss_rel_err=abs(loss - ref_loss) / abs(ref_loss), worst_grad_err=gmax, worst_grad=gmax_name,
+                       grad_metric="max-abs/max" if dtype == "f32" else "rel-L2", decode_equal=dec_same))
+    if dtype == "f32":
+        assert lerr <= 1e-4, f"logits max-abs-err {lerr:.3e}"
+        assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-4, (loss, ref_loss)
+    else:
+        assert lerr <= bf16_tol["logits"], f"logits max-abs-err {lerr:.3e}"
+        assert abs(loss - ref_loss) <= bf16_tol["loss"] * abs(ref_loss), (loss, ref_loss)
     assert not bad, f"gradient mismatch ({len(bad)}/{len(ref_grads)}): {sorted(bad, key=lambda t: -t[1])[:8]}"
     # BatchNorm moving statistics were updated in place by the training forward
     for n, rs in ref_stats.items():
-        tol = 1e-4 if dtype == "f32" else 3e-2
+        tol = 1e-4 if dtype == "f32" else bf16_tol["stats"]
         assert np.abs(W_after[n] - rs).max() <= tol * (1 + np.abs(rs).max()), n
+    if check_decode:
+        assert dec_same, "greedy decode indices differ from the oracle's on clips without a near-tie frame"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CFGS))
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_train_step_parity(name, dtype, dropout):
+    check_train_step(CFGS[name], dtype, dropout, f"train_step[{name}]")
 
 
 def test_label_edge_cases():
