@@ -23,6 +23,9 @@ typedef struct ishara_model ishara_model;
 typedef void* ishara_stream;              /* hipStream_t */
 
 enum { ISHARA_F32 = 0, ISHARA_BF16 = 1 };
+/* model families behind one handle type: the Keras hybrid of get_model (conv-hybrid-model.ipynb c7:1-72) and the torch
+ * ConformerEncoder of conformer/conformer.py:76-87 (post-LN blocks, encoder stack only) */
+enum { ISHARA_FAMILY_KERAS_HYBRID = 0, ISHARA_FAMILY_TORCH_CONFORMER = 1 };
 
 /* get_model(...) kwargs — conv-hybrid-model.ipynb c7:1-11 — plus the notebook globals the
  * function closes over (INPUT_SHAPE c3:119, len(char_to_num) c1:7) and the variant knobs
@@ -50,6 +53,8 @@ typedef struct ishara_config {
     int32_t max_batch;              /* workspace is planned for this many clips */
     int32_t max_label_len;          /* MAX_PHRASE_LENGTH = 64 (c1:28) */
     int32_t attn_impl;              /* 0 lane-split VALU, 1 MFMA (bf16 only) */
+    int32_t family;                 /* ISHARA_FAMILY_*.  TORCH_CONFORMER reads: dim, num_conv_conform_blocks (= num_layers), num_heads,
+                                     * expansion_factor, transformer_kernel_size (= kernel_size, odd), dropout_rate, frames, dtype, max_batch */
 } ishara_config;
 
 const char* ishara_last_error(void);
@@ -84,6 +89,13 @@ int ishara_forward(ishara_model* m, const float* x, int32_t B, float* logits, in
  * loss (device scalar) = mean_b nll_b; gradients of loss*loss_scale fill grads[0,trainable). */
 int ishara_loss_backward(ishara_model* m, const float* logits, const int64_t* labels, int32_t B,
                          float* loss, float* nll, float loss_scale, ishara_stream s);
+/* ConformerEncoder.forward (conformer/conformer.py:84-87) for an ISHARA_FAMILY_TORCH_CONFORMER handle: x, y [B,T,dim] f32.
+ * training=1: Dropout active (seed), BatchNorm1d uses batch statistics and updates running_mean / running_var, the
+ * activations the backward pass needs stay in the workspace. */
+int ishara_encoder_forward(ishara_model* m, const float* x, int32_t B, float* y, int32_t training, uint32_t seed, ishara_stream s);
+/* loss.backward() through the encoder (conformer.py:99-103): dy [B,T,dim] f32 = dLoss/dy of the last ishara_encoder_forward(training=1);
+ * parameter gradients fill grads[0,trainable) (overwritten); dx [B,T,dim] f32 may be NULL. */
+int ishara_encoder_backward(ishara_model* m, const float* dy, int32_t B, float* dx, ishara_stream s);
 /* Gradient buckets for data parallelism (replaces what tf.distribute / nn.DataParallel do inside the reference's
  * train step: nb4 c1:63-75, integration.py:1058-1060).  The backward pass completes the flat gradient from its end
  * (head) towards its start (stem); ishara_grad_bucket(i) gives range i in completion order and

@@ -4,3 +4,4 @@ model.fit surface.  See DESIGN.md and include/ishara_hip.h."""
 from .model import (Callback, History, LearningRateScheduler, Model, Optimizer, PAD_TOKEN_IDX,  # noqa: F401
                     get_model, lrfn, make_config)
 from ._lib import IsharaError  # noqa: F401
+from .conformer import ConformerEncoder  # noqa: F401  (torch family: conformer/conformer.py)

@@ -959,7 +959,7 @@ DEVI double fin_fold(double v) {
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nb, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ mmean, float* __restrict__ mvar, int training,
-                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ bsh, int C) {
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ bsh, int C, float var_corr) {
     __shared__ double rs_[FIN_NW][FIN_CL], rq_[FIN_NW][FIN_CL];
     const int cl = threadIdx.x & (FIN_CL - 1), bl = threadIdx.x / FIN_CL, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * FIN_CL + cl;
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         if (v < 0.0) v = 0.0;
         mu = (float)m; var = (float)v;
         mmean[c] = mmean[c] * momentum + mu * (1.f - momentum);
-        mvar[c] = mvar[c] * momentum + var * (1.f - momentum);
+        mvar[c] = mvar[c] * momentum + var * var_corr * (1.f - momentum);
     } else { mu = mmean[c]; var = mvar[c]; }
     const float rs = rsqrtf(var + eps);
     mean[c] = mu; rstd[c] = rs;
@@ -988,9 +988,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 
 int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count, const float* gamma, const float* beta,
                           float eps, float momentum, float* moving_mean, float* moving_var, int training,
-                          float* mean, float* rstd, float* a, float* b, int C, hipStream_t s) {
+                          float* mean, float* rstd, float* a, float* b, int C, hipStream_t s, float var_corr) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, ssum, ssq, nb, count, gamma, beta, eps, momentum,
-                       moving_mean, moving_var, training, mean, rstd, a, b, C);
+                       moving_mean, moving_var, training, mean, rstd, a, b, C, var_corr);
     return LAUNCH_OK();
 }
 

@@ -92,7 +92,8 @@ int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const flo
 // a = gamma*rstd, b = beta - mean*a ; moving statistics update when training
 int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count, const float* gamma, const float* beta,
                        float eps, float momentum, float* moving_mean, float* moving_var, int training,
-                       float* mean, float* rstd, float* a, float* b, int C, hipStream_t s);
+                       float* mean, float* rstd, float* a, float* b, int C, hipStream_t s, float var_corr = 1.f);   // var_corr: factor on the batch variance
+                                                                                                                       // entering moving_var (torch: n/(n-1))
 // ECA fwd on [B,C]: g = a*gap/T + b ; s = sigmoid(conv5(g)) ; P = a*s ; Q = b*s
 int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
                    float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s);

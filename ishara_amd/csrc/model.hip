@@ -2,15 +2,7 @@
 // (conv-hybrid-model.ipynb c7:12-65), its flat parameter layout, the workspace plan and the
 // forward / backward / optimizer orchestration over the kernels in gemm.hip, elementwise.hip,
 // attention.hip, ctc.hip and optimizer.hip.  Everything is launched on the caller's stream.
-#include <stdarg.h>
-#include <stdio.h>
-#include <string.h>
-#include <math.h>
-#include <string>
-#include <vector>
-#include <map>
-#include "kernels.h"
-#include "../../include/ishara_hip.h"
+#include "model_types.h"
 
 // ------------------------------------------------------------------ error string
 static thread_local char g_err[1024] = "";
@@ -21,23 +13,6 @@ void ishara_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* ishara_last_error(void) { return g_err; }
-
-#define CK(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
-// profiled launch: key = kernel family, by = algorithmic bytes, fl = flops of this launch
-#define CKP(m, key, by, fl, expr)                                                          \
-    do {                                                                                   \
-        ProfRec* _pr = nullptr;                                                            \
-        if ((m)->prof.on) {                                                                \
-            (m)->prof.recs.push_back(ProfRec{key, (m)->prof.get(), (m)->prof.get(), (double)(by), (double)(fl)}); \
-            _pr = &(m)->prof.recs.back();                                                  \
-            (void)hipEventRecord(_pr->e0, (m)->s);                                         \
-        }                                                                                  \
-        int _r = (expr);                                                                   \
-        if (_pr) (void)hipEventRecord(_pr->e1, (m)->s);                                    \
-        if (_r != 0) return _r;                                                            \
-    } while (0)
-
-static inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------ small kernels
 // fills inside forward / backward use a kernel rather than hipMemsetAsync: under hipGraph capture the memset NODES of this
@@ -78,129 +53,6 @@ __global__ void qkv_split_kernel(const T* qkv, T* q, T* k, T* vt, int B, int H, 
         else vt[((size_t)(b * H + h) * dh + e) * Tn + t] = v;
     }
 }
-
-// ------------------------------------------------------------------ model description
-struct ParamEntry { std::string name; int ndim; int64_t shape[2]; int64_t offset; bool trainable; };
-
-struct DenseW {           // a Dense / 1x1-conv weight [K,N] (+bias) with its MFMA shadows
-    int w = -1, b = -1, K = 0, N = 0;
-    size_t wt = 0, wn = 0;    // byte offsets in the workspace
-    int ldt = 0, ldn = 0;
-};
-struct Norm { int gamma = -1, beta = -1; };
-struct BNp { int gamma = -1, beta = -1, mm = -1, mv = -1; };
-
-struct Buf { size_t off = 0; };   // byte offset in the workspace
-
-struct ConvBlock {
-    DenseW W1, W2; int dw = -1, eca = -1; BNp bn; int k = 0; uint32_t site = 0;
-    Buf z1, h2, h4, out, ssum, ssq, mean, rstd, a, bsh, gn, sg, P, Q, rs;
-};
-struct FFN {
-    Norm ln; float eps; DenseW Wa, Wb; uint32_t site_in = 0, site_out = 0; bool has_out_drop = false;
-    Buf xn, mean, rstd, za, u, out;
-};
-struct MHSA {
-    Norm ln; float eps; DenseW Wqkv, Wp; float rate = 0.f; uint32_t site_attn = 0, site_out = 0; bool has_out_drop = false;
-    Buf xn, mean, rstd, q, k, vt, o, lse, out, maskw;
-};
-struct SqzConv {
-    Norm ln; DenseW Wc1, Wc3; int dw = -1, seW1 = -1, seb1 = -1, seW2 = -1, seb2 = -1; int k = 0, R = 0;
-    Buf xn, mean, rstd, zc, zd, hd, u3, gap, hid, se, out;
-};
-struct ConfConv {
-    DenseW Wp1, Wp2; int dw = -1, dwb = -1; BNp bn; Norm ln; int k = 0;
-    Buf g, v, bnv, ssum, ssq, mean, rstd, a, bsh, r, lnmean, lnrstd, out;
-};
-struct Layer {            // one entry of the sequential graph
-    enum Kind { CONV, SQZ, CONF } kind;
-    int idx;
-};
-struct SqzBlock { FFN ffn1; MHSA mha; SqzConv conv; FFN ffn2; };
-struct ConfBlock { FFN ffn1; MHSA mha; ConfConv conv; FFN ffn2; };
-
-// HIP-event profiler: when enabled every kernel launch site records a (start, stop) event pair
-// on the launch stream plus the algorithmic bytes / flops of that launch (bench.py roofline).
-struct ProfRec { const char* key; hipEvent_t e0, e1; double bytes, flops; };
-struct Profiler {
-    bool on = false;
-    std::vector<ProfRec> recs;
-    std::vector<hipEvent_t> pool;
-    size_t used = 0;
-    hipEvent_t get() {
-        if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
-        return pool[used++];
-    }
-};
-
-struct ishara_model {
-    ishara_config cfg;
-    Profiler prof;
-    int dt;                       // activation / MFMA dtype
-    int d, T, F, C, H, dh, dtop, Bmax, L;
-    std::vector<ParamEntry> entries;
-    int64_t n_total = 0, n_train = 0;
-    // graph
-    DenseW stemW; BNp stem_bn;
-    // gradient buckets for an overlapped all-reduce: ranges of the flat gradient, in the order the backward pass completes them
-    std::vector<int64_t> bucket_lo, bucket_hi; std::vector<int> bucket_after_layer; std::vector<hipEvent_t> bucket_ev;
-    std::vector<size_t> layer_entry_end; size_t stem_entry_end = 0;
-    int cls_pad = 0; Buf dlb;          // bf16 model: dlogits also as bf16 [M, cls_pad] (zero padded), 0 = f32 operand path
-    int stem_kp = 0; Buf stem_xb;      // bf16 model: input rows packed to bf16 [M, stem_kp] (zero padded), 0 = f32-A GEMM path
-    Buf stem_h0, stem_out, stem_ssum, stem_ssq, stem_mean, stem_rstd, stem_a, stem_bsh, pe;
-    std::vector<ConvBlock> convs;
-    std::vector<SqzBlock> sqz;
-    std::vector<ConfBlock> conf;
-    std::vector<Layer> layers;
-    DenseW topW, clsW; uint32_t head_site = 0; Buf head_hh;
-    uint32_t nsites = 0;
-    std::vector<DenseW*> denses;
-    // temps
-    Buf gA, gB, t1, t2, t3, S1, S2, E, Fc, Ecol, ecap, dse, dgapT, slab, ctcws, dlogits, nllb, delta;
-    size_t shadow_begin = 0, shadow_end = 0;
-    size_t shadow_tab_off = 0;             // device descriptor table of the batched shadow build, inside the workspace (no
-                                           // hipMalloc/hipFree of our own: a hipFree from a garbage-collected model would break a
-                                           // stream capture in progress elsewhere in the process)
-    std::vector<ShadowDesc> shadow_tab_host;
-    int shadow_ntab = 0, shadow_tiles = 0;
-    bool shadow_ready = false;
-    size_t ws_need = 0;
-    // bound
-    float* params = nullptr; float* grads = nullptr; float* om = nullptr; float* ov = nullptr; float* oslow = nullptr;
-    char* ws = nullptr; int64_t ws_bytes = 0;
-    std::vector<float> pe_host;
-    // run state
-    int lastB = 0; int last_training = 0; uint32_t last_seed = 0; const float* last_x = nullptr;
-    int opt_iter = 0;
-    hipStream_t s = nullptr;
-
-    // ---- build helpers
-    int addp(const std::string& name, int64_t r, int64_t c, bool trainable) {
-        ParamEntry e; e.name = name; e.ndim = c > 0 ? 2 : 1; e.shape[0] = r; e.shape[1] = c > 0 ? c : 0; e.offset = -1; e.trainable = trainable;
-        entries.push_back(e);
-        return (int)entries.size() - 1;
-    }
-    size_t cur = 0;
-    Buf alloc(size_t bytes) { Buf b; b.off = cur; cur = rup(cur + bytes, 256); return b; }
-    Buf act(int cols) { return alloc((size_t)Bmax * T * cols * dt_size(dt)); }
-    Buf f32(size_t n) { return alloc(n * sizeof(float)); }
-    DenseW dense(const std::string& name, int K, int N, bool bias) {
-        DenseW w; w.K = K; w.N = N;
-        w.w = addp(name + "/kernel", K, N, true);
-        if (bias) w.b = addp(name + "/bias", N, 0, true);
-        return w;
-    }
-    Norm norm(const std::string& name, int c) { Norm n; n.gamma = addp(name + "/gamma", c, 0, true); n.beta = addp(name + "/beta", c, 0, true); return n; }
-    BNp bnp(const std::string& name, int c) {
-        BNp b; b.gamma = addp(name + "/gamma", c, 0, true); b.beta = addp(name + "/beta", c, 0, true);
-        b.mm = addp(name + "/moving_mean", c, 0, false); b.mv = addp(name + "/moving_variance", c, 0, false);
-        return b;
-    }
-    float* P(int idx) const { return params + entries[idx].offset; }
-    float* G(int idx) const { return grads + entries[idx].offset; }
-    template <typename TT = void> TT* W(Buf b) const { return reinterpret_cast<TT*>(ws + b.off); }
-    float* Wf(Buf b) const { return reinterpret_cast<float*>(ws + b.off); }
-};
 
 // ------------------------------------------------------------------ construction
 static void build_conv(ishara_model* m, const std::string& name, int k) {
@@ -337,7 +189,7 @@ static void build_graph(ishara_model* m) {
     }
 }
 
-static void plan_shadow(ishara_model* m, DenseW& w, int min_ldt = 0, int min_ldn = 0) {
+void plan_shadow(ishara_model* m, DenseW& w, int min_ldt, int min_ldn) {
     const int bk = m->dt == DT_BF16 ? 64 : 32;
     const size_t es = dt_size(m->dt);
     w.ldt = (int)rup(w.K, bk);
@@ -441,6 +293,13 @@ static void plan_workspace(ishara_model* m) {
 extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     if (!cfg || !out) { ishara_set_error("ishara_create: null argument"); return -1; }
     ishara_config c = *cfg;
+    if (c.family != ISHARA_FAMILY_KERAS_HYBRID && c.family != ISHARA_FAMILY_TORCH_CONFORMER) { ishara_set_error("family=%d unknown", c.family); return -1; }
+    if (c.family == ISHARA_FAMILY_TORCH_CONFORMER) {      // conformer/conformer.py: no stem, no head, no CTC — the encoder stack only
+        CK(r5_validate(c));
+        c.features = c.dim; c.num_conv_per_block = 0; c.num_conv_squeeze_blocks = 0;
+        if (c.num_classes <= 0) c.num_classes = 60;
+        if (c.num_kernel_sizes <= 0) { c.num_kernel_sizes = 1; c.kernel_sizes[0] = 3; }
+    }
     if (c.dim <= 0 || c.dim % 8 != 0 || c.dim > 512) { ishara_set_error("dim=%d unsupported (multiple of 8, <=512)", c.dim); return -1; }
     if (c.num_heads <= 0 || c.dim % c.num_heads != 0) { ishara_set_error("dim %% num_heads != 0"); return -1; }
     const int dh = c.dim / c.num_heads;
@@ -462,6 +321,8 @@ extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     m->cfg = c; m->dt = c.dtype == ISHARA_BF16 ? DT_BF16 : DT_F32;
     m->d = c.dim; m->T = c.frames; m->F = c.features; m->C = c.num_classes; m->H = c.num_heads; m->dh = dh;
     m->dtop = c.top_dim; m->Bmax = c.max_batch; m->L = c.max_label_len;
+    m->family = c.family;
+    if (m->family == ISHARA_FAMILY_TORCH_CONFORMER) { r5_build_graph(m); r5_plan_workspace(m); *out = m; return 0; }
     build_graph(m);
     plan_workspace(m);
     // positional encoding table (c5:226-235): [sin | cos] halves, fp32 arithmetic
@@ -504,7 +365,7 @@ extern "C" int ishara_bind(ishara_model* m, float* params, float* grads, float* 
     m->params = params; m->grads = grads; m->om = opt_m; m->ov = opt_v; m->oslow = opt_slow;
     m->ws = (char*)workspace; m->ws_bytes = workspace_bytes;
     m->shadow_ready = false;               // new buffers: rebuild the descriptor table and re-zero the padding
-    HIP_CHECK_RET(hipMemcpy(m->ws + m->pe.off, m->pe_host.data(), m->pe_host.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (m->family == ISHARA_FAMILY_KERAS_HYBRID) HIP_CHECK_RET(hipMemcpy(m->ws + m->pe.off, m->pe_host.data(), m->pe_host.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -535,18 +396,18 @@ extern "C" int ishara_sync_weights(ishara_model* m, ishara_stream st) {
 }
 
 // ------------------------------------------------------------------ GEMM wrappers
-static int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea) {
+int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea) {
     if (w.b >= 0) ea.bias = m->P(w.b);
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtC) * (1 + (ea.resid ? 1 : 0) + (ea.pre_out ? 1 : 0)) + (double)w.K * w.N * dt_size(m->dt);
     CKP(m, gemm_nt_kernel_name(dtA, m->dt, dtC, aop, A, M, w.N, w.K, w.ldt, ea), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, dtC, aop, A, m->ws + w.wt, Cc, M, w.N, w.K, w.ldt, oa, ea, m->s));
     return 0;
 }
-static int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea) {
+int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea) {
     const double by = (double)M * w.N * dt_size(dtA) + (double)M * w.K * dt_size(m->dt) * (1 + (ea.resid ? 1 : 0) + (ea.aux ? 1 : 0)) + (double)w.K * w.N * dt_size(m->dt);
     CKP(m, gemm_nt_kernel_name(dtA, m->dt, m->dt, aop, dY, M, w.K, w.N, w.ldn, ea), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
     return 0;
 }
-static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0, int nb_valid = 0) {
+int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid, int nb_valid) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
     // the GEMM kernel and the sums of its split-M slabs are profiled under separate keys (the kernel's key is its rocprof name)
     g_tn_phase = 1;
@@ -557,8 +418,6 @@ static int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, 
     return 0;
 }
 
-struct Run { int B, M, training; uint32_t seed; };
-static DropSpec dspec(const Run& r, uint32_t site, float rate) { return make_drop(r.seed, site, rate, r.training != 0); }
 
 // ------------------------------------------------------------------ module forward
 static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x) {
@@ -621,22 +480,24 @@ static int sqzconv_fwd(ishara_model* m, SqzConv& c, const Run& r, const void* x)
     return 0;
 }
 
-static int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x) {
+int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
     CK(gemm_fwd(m, c.Wp1, x, dt, m->W(c.g), dt, r.M, OP_NONE, no, e0));
     CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));
-    CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), 1e-3f, 0.99f,
-                          m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s));
+    const float var_corr = c.bn_unbiased && B * T > 1 ? (float)((double)B * T / ((double)B * T - 1.0)) : 1.f;
+    CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), c.bn_eps, c.bn_keep,
+                          m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s, var_corr));
     CKP(m, "col_affine", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_col_affine(dt, m->W(c.v), m->Wf(c.a), m->Wf(c.bsh), m->W(c.bnv), r.M, d, m->s));
     EpiArgs e2; e2.resid = x;
     CK(gemm_fwd(m, c.Wp2, m->W(c.bnv), dt, m->W(c.r), dt, r.M, OP_NONE, no, e2));
-    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, m->W(c.r), m->P(c.ln.gamma), m->P(c.ln.beta), 1e-3f, m->W(c.out), m->Wf(c.lnmean), m->Wf(c.lnrstd), r.M, d, m->s));
+    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, m->W(c.r), m->P(c.ln.gamma), m->P(c.ln.beta), c.ln_eps, m->W(c.out), m->Wf(c.lnmean), m->Wf(c.lnrstd), r.M, d, m->s));
     return 0;
 }
 
 extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float* logits, int32_t training, uint32_t seed, ishara_stream st) {
     if (!m->ws) { ishara_set_error("ishara_forward: model is not bound"); return -1; }
+    if (m->family != ISHARA_FAMILY_KERAS_HYBRID) { ishara_set_error("ishara_forward: this handle is an encoder-only family; use ishara_encoder_forward"); return -1; }
     if (B <= 0 || B > m->Bmax) { ishara_set_error("ishara_forward: batch %d outside 1..%d", B, m->Bmax); return -1; }
     m->s = (hipStream_t)st;
     Run r{B, B * m->T, training, seed};
@@ -765,7 +626,7 @@ static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x,
     return 0;
 }
 
-static int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn) {
+int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
     CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), m->Wf(m->slab), r.M, d, m->s));   // dr
@@ -783,6 +644,7 @@ static int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* 
 
 extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const int64_t* labels, int32_t B, float* loss, float* nll, float loss_scale, ishara_stream st) {
     if (!m->ws || !m->grads) { ishara_set_error("ishara_loss_backward: model is not bound (grads required)"); return -1; }
+    if (m->family != ISHARA_FAMILY_KERAS_HYBRID) { ishara_set_error("ishara_loss_backward: this handle is an encoder-only family; use ishara_encoder_backward"); return -1; }
     if (B != m->lastB || !m->last_training) { ishara_set_error("ishara_loss_backward: call ishara_forward(training=1) with the same batch first"); return -1; }
     m->s = (hipStream_t)st;
     Run r{B, B * m->T, 1, m->last_seed};

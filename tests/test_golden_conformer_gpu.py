@@ -120,3 +120,96 @@ def test_hip_kernels_reproduce_reference_conformer_outputs(lib, dt):
         err = float(np.abs(taps["out"].float().cpu().numpy().reshape(B, T, d) - G[f"blk{i}_out"]).max())
         assert err <= tol, f"block {i} output: max-abs-err {err:.3e}"
         x = taps["out"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The product path: ishara_amd.ConformerEncoder (csrc/conformer_r5.hip through ishara_encoder_forward / _backward)
+# against the same reference-generated vectors — eval-mode outputs per block, and the TRAINING-mode pass of the fixture
+# (BatchNorm1d batch statistics on the GPU, nothing folded on the host): output, input gradient and every parameter
+# gradient of the reference's own autograd.
+# ---------------------------------------------------------------------------------------------------------------------
+def _encoder(dt, layers, dropout=0.0):
+    from ishara_amd.conformer import ConformerEncoder
+    d, _, heads, ksize, exp = [int(v) for v in G["cfg"]]
+    B, T, _ = G["x"].shape
+    enc = ConformerEncoder(d, layers, heads, exp, ksize, dropout, seq_len=T, max_batch=B, dtype=dt)
+    sd = {k[3:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("sd/")}
+    enc.load_state_dict({k: v for k, v in sd.items() if int(k.split(".")[1]) < layers})
+    return enc
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_product_encoder_eval_matches_reference(dt):
+    layers = int(G["cfg"][1])
+    enc = _encoder(dt, layers).eval()
+    y = enc(torch.from_numpy(G["x"])).cpu().numpy()
+    err = float(np.abs(y - G[f"blk{layers - 1}_out"]).max())
+    assert err <= (1e-4 if dt == "f32" else 0.08), f"encoder output max-abs-err {err:.3e}"
+    # eval mode leaves the running statistics untouched
+    after = enc.state_dict()
+    assert np.array_equal(after["layers.0.conv.batch_norm.running_mean"].numpy(), G["sd/layers.0.conv.batch_norm.running_mean"])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_product_encoder_training_pass_matches_reference_autograd(dt):
+    enc = _encoder(dt, 1).train()
+    x = torch.from_numpy(G["x"]).cuda().requires_grad_(True)
+    y = enc(x)
+    (y * torch.from_numpy(G["train_G"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    yerr = float(np.abs(y.detach().cpu().numpy() - G["train_y"]).max())
+    assert yerr <= (1e-4 if dt == "f32" else 0.08), f"training-mode output max-abs-err {yerr:.3e}"
+    dx, want_dx = x.grad.cpu().numpy(), G["train_dx"]
+    if dt == "f32":
+        assert np.abs(dx - want_dx).max() <= 1e-3 * np.abs(want_dx).max()
+    else:
+        assert np.linalg.norm(dx - want_dx) <= 0.08 * np.linalg.norm(want_dx)
+    grads = enc.grad_state_dict()
+    names = [k[len("train_grad/"):] for k in G.files if k.startswith("train_grad/")]
+    assert sorted(names) == sorted(grads)
+    gscale = max(float(np.abs(G["train_grad/" + n]).max()) for n in names)
+    bad = []
+    for n in names:
+        want, got = G["train_grad/" + n], grads[n].numpy()
+        assert got.shape == want.shape, n
+        if np.abs(want).max() < 1e-6 * gscale:             # analytically zero (depthwise bias in front of BatchNorm)
+            if np.abs(got).max() > (1e-3 if dt == "f32" else 3e-2) * gscale: bad.append((n, float(np.abs(got).max())))
+        elif dt == "f32":
+            e = float(np.abs(got - want).max() / np.abs(want).max())
+            if e > 1e-3: bad.append((n, e))
+        else:
+            e = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+            if e > 0.1: bad.append((n, e))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:8]
+    # flat.grad (what a torch optimiser steps) is the library's gradient buffer
+    assert torch.equal(enc.flat.grad, enc.grads[:enc.n_train])
+    # BatchNorm1d running statistics: momentum 0.1 on the new value, unbiased variance
+    sd_after = enc.state_dict()
+    assert not np.array_equal(sd_after["layers.0.conv.batch_norm.running_var"].numpy(), G["sd/layers.0.conv.batch_norm.running_var"])
+
+
+def test_product_encoder_running_stats_follow_torch_rule():
+    """nn.BatchNorm1d (conformer.py:43): running = 0.9 running + 0.1 batch, with the UNBIASED batch variance — checked against
+    the oracle restatement's conv module evaluated on the same block input."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import conformer_torch_oracle as RO
+    enc = _encoder("f32", 1).train()
+    sd = {k[3:]: torch.from_numpy(G[k]).double() for k in G.files if k.startswith("sd/layers.0.")}
+    x = torch.from_numpy(G["x"]).double()
+    with torch.no_grad():
+        a = RO.ffn(x, sd, "layers.0.ffn1"); b = RO.mhsa(a, sd, "layers.0.attention", int(G["cfg"][2]))
+        p = "layers.0.conv"
+        d = x.shape[-1]
+        u = b @ sd[p + ".pointwise_conv1.weight"][:, :, 0].t() + sd[p + ".pointwise_conv1.bias"]
+        u = u[..., :d] * torch.sigmoid(u[..., d:])
+        w = sd[p + ".depthwise_conv.weight"]
+        u = torch.nn.functional.conv1d(u.transpose(1, 2), w, sd[p + ".depthwise_conv.bias"], padding=w.shape[-1] // 2, groups=d).transpose(1, 2)
+        mean, var = u.mean(dim=(0, 1)), u.reshape(-1, d).var(dim=0, unbiased=True)
+    with torch.no_grad():
+        enc(torch.from_numpy(G["x"]))
+    after = enc.state_dict()
+    want_m = 0.9 * sd[p + ".batch_norm.running_mean"] + 0.1 * mean
+    want_v = 0.9 * sd[p + ".batch_norm.running_var"] + 0.1 * var
+    np.testing.assert_allclose(after[p + ".batch_norm.running_mean"].numpy(), want_m.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(after[p + ".batch_norm.running_var"].numpy(), want_v.numpy(), rtol=0, atol=2e-5)
