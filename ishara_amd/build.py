@@ -9,6 +9,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 
 
+def source_hash() -> str:
+    """Hash of every source the library is built from (csrc/*.hip, *.h, the public header): stamps profiles/*_traffic.json so
+    bench.py only quotes PMC traffic measured on the build it is running."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "ishara_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose: bool = True, jobs: int = 8) -> str:
     cmd = ["make", "-C", CSRC, f"-j{jobs}"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

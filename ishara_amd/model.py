@@ -296,6 +296,10 @@ class Model:
         overlap = world > 1 and parallel.overlap_enabled()
         if overlap:
             self.enable_grad_buckets()
+        if seed is None and world > 1:
+            # replicas share the weight-initialisation seed but draw independent dropout / drop-path masks for their shards,
+            # like the reference's replicas (tf.distribute / nn.DataParallel keep per-replica RNG streams)
+            seed = ((self._step_seed + 0x9E3779B1 * self._steps) ^ (parallel.rank() * 0x85EBCA6B)) & 0xFFFFFFFF
         loss, _ = self.loss_and_gradients(x, y, seed=seed, loss_scale=1.0 / world)
         if overlap:
             parallel.allreduce_buckets_(self)          # ranges of the gradient reduced on a side stream as the backward pass finishes them

@@ -65,24 +65,34 @@ def overlap_enabled() -> bool:
 _side_streams = {}
 
 
+def allreduce_ranges_(flat: torch.Tensor, ranges, before_range=None) -> None:
+    """Sum over ranks of `flat[off:off+cnt]` for every (off, cnt) in `ranges`, one asynchronous collective per non-empty
+    range, issued in the given order and all waited for before returning.  `before_range(i)` runs right before range i's
+    collective is enqueued (the GPU path makes the side stream wait for that range's completion event there).  Device
+    agnostic: the ordering logic is what tests/test_parallel_gloo.py checks against the flat all-reduce with 3 gloo ranks."""
+    works = []
+    for i, (off, cnt) in enumerate(ranges):
+        if cnt <= 0:
+            continue
+        if before_range is not None:
+            before_range(i)
+        works.append(dist.all_reduce(flat[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+
+
 def allreduce_buckets_(model) -> None:
     """Sum over ranks of model.grads[:n_train], one collective per gradient bucket.  The backward pass is already enqueued on
     the current stream when this is called; bucket i's collective is enqueued on a side stream that waits only for the event the
     library recorded when that range became final, so it runs while the rest of the backward pass executes.  The current
-    stream waits for all of them at the end (before the optimizer step)."""
+    stream waits for all of them at the end (before the optimizer step).  NOT yet validated over RCCL on a multi-GPU node
+    (only over gloo): off by default, see overlap_enabled()."""
     dev = model.grads.device
     side = _side_streams.get(dev)
     if side is None:
         side = _side_streams[dev] = torch.cuda.Stream(device=dev)
-    works = []
-    for i, (off, cnt) in enumerate(model.grad_buckets()):
-        if cnt <= 0:
-            continue
-        model.wait_grad_bucket(i, side)
-        with torch.cuda.stream(side):
-            works.append(dist.all_reduce(model.grads[off:off + cnt], op=dist.ReduceOp.SUM, async_op=True))
-    for w in works:
-        w.wait()                                   # current stream <- collective
+    with torch.cuda.stream(side):
+        allreduce_ranges_(model.grads, model.grad_buckets(), before_range=lambda i: model.wait_grad_bucket(i, side))   # w.wait(): side <- collective
     torch.cuda.current_stream(dev).wait_stream(side)
 
 

@@ -71,3 +71,53 @@ def test_shard_batch_partition():
     parts = [parallel.shard_batch(x, x, r, 4)[0] for r in range(4)]
     assert sorted(np.concatenate(parts)[:, 0].tolist()) == x[:, 0].tolist()
     assert parallel.world_size() == 1 and parallel.rank() == 0
+
+
+def _bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from ishara_amd import parallel
+    parallel.init_from_env("gloo")
+    n = 100_003
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randint(-1000, 1000, (n,), generator=g).float()          # integers: sums are exact whatever order gloo adds in
+    want = flat.clone()
+    parallel.allreduce_sum_(want)
+    # head -> stem completion order, an empty range, an uneven last bucket; together they tile [0, n)
+    ranges = [(70_000, 30_003), (69_999, 1), (40_000, 29_999), (40_000, 0), (0, 40_000)]
+    seen = []
+    got = flat.clone()
+    parallel.allreduce_ranges_(got, ranges, before_range=seen.append)
+    untouched = flat.clone()
+    parallel.allreduce_ranges_(untouched, [(10, 0)])
+    ok = torch.equal(got, want) and seen == [0, 1, 2, 4] and torch.equal(untouched, flat)
+    res = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(res, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        np.save(out, res.numpy())
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_flat_with_three_ranks(tmp_path):
+    """allreduce_ranges_ (the ordering logic of the overlapped bucketed all-reduce) against the flat all-reduce: 3 ranks,
+    bucket boundaries in completion order, an empty range, an uneven last bucket."""
+    world, port = 3, 30011 + os.getpid() % 500
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    assert np.load(out)[0] == 1.0
+
+
+def test_grad_buckets_tile_the_trainable_range():
+    """ishara_grad_bucket ranges of the library (host only, no GPU): disjoint, in head -> stem order, covering [0, n_train)."""
+    from ishara_amd import make_config
+    from ishara_amd.model import Model
+    for kw in (dict(dim=256, input_shape=(384, 224)), dict(dim=64, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1)):
+        m = Model(make_config(**kw, max_batch=2), device=None)
+        b = m.grad_buckets()
+        assert 1 <= len(b) <= 4
+        hi = m.n_train
+        for off, cnt in b:
+            assert cnt > 0 and off + cnt == hi
+            hi = off
+        assert hi == 0
