@@ -73,6 +73,12 @@ int  ishara_param_info(const ishara_model* m, int32_t i, const char** name, int3
                        int64_t shape[2], int64_t* offset, int32_t* trainable);
 int64_t ishara_workspace_bytes(const ishara_model* m);
 
+/* Debug aids (no reference counterpart).  plan_check: host-side audit of the workspace plan (alignment, bounds, no overlap);
+ * returns the buffer count.  guard_check: with ISHARA_WS_GUARD=1 in the environment at ishara_create every workspace buffer is
+ * followed by a 256-byte guard zone armed by ishara_bind; returns 0 if all guards are intact (synchronises the device). */
+int32_t ishara_workspace_plan_check(const ishara_model* m);
+int ishara_workspace_guard_check(ishara_model* m);
+
 /* Bind caller-owned device buffers.  params/grads: ishara_param_total floats (grads only
  * uses the trainable prefix); opt_m/opt_v/opt_slow: ishara_param_trainable floats each
  * (may be NULL for inference); workspace: ishara_workspace_bytes bytes, 256-B aligned. */

@@ -43,6 +43,8 @@ SIGNATURES = {
     "ishara_param_entries": (_I32, [_P]),
     "ishara_param_info": (C.c_int, [_P, _I32, C.POINTER(C.c_char_p), C.POINTER(_I32), C.POINTER(_I64 * 2), C.POINTER(_I64), C.POINTER(_I32)]),
     "ishara_workspace_bytes": (_I64, [_P]),
+    "ishara_workspace_plan_check": (_I32, [_P]),
+    "ishara_workspace_guard_check": (C.c_int, [_P]),
     "ishara_grad_buckets": (_I32, [_P]),
     "ishara_grad_bucket": (C.c_int, [_P, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ishara_grad_buckets_enable": (C.c_int, [_P]),

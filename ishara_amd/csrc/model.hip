@@ -3,6 +3,8 @@
 // forward / backward / optimizer orchestration over the kernels in gemm.hip, elementwise.hip,
 // attention.hip, ctc.hip and optimizer.hip.  Everything is launched on the caller's stream.
 #include "model_types.h"
+#include <algorithm>
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ error string
 static thread_local char g_err[1024] = "";
@@ -322,6 +324,7 @@ extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     m->d = c.dim; m->T = c.frames; m->F = c.features; m->C = c.num_classes; m->H = c.num_heads; m->dh = dh;
     m->dtop = c.top_dim; m->Bmax = c.max_batch; m->L = c.max_label_len;
     m->family = c.family;
+    { const char* gv = getenv("ISHARA_WS_GUARD"); m->guard = gv && gv[0] == '1'; }
     if (m->family == ISHARA_FAMILY_TORCH_CONFORMER) { r5_build_graph(m); r5_plan_workspace(m); *out = m; return 0; }
     build_graph(m);
     plan_workspace(m);
@@ -357,6 +360,40 @@ extern "C" int ishara_param_info(const ishara_model* m, int32_t i, const char** 
     return 0;
 }
 extern "C" int64_t ishara_workspace_bytes(const ishara_model* m) { return (int64_t)m->ws_need; }
+// Host-side audit of the workspace plan: every buffer 256-byte aligned, inside [0, workspace_bytes), no two buffers (or guard
+// zones) overlapping.  Returns the number of buffers, <0 on a violation.
+extern "C" int32_t ishara_workspace_plan_check(const ishara_model* m) {
+    std::vector<std::pair<size_t, size_t>> r = m->allocs;
+    for (size_t off : m->guard_offs) r.push_back({off, 256});
+    std::sort(r.begin(), r.end());
+    size_t end = 0;
+    for (auto& a : r) {
+        if (a.first % 256 != 0) { ishara_set_error("workspace buffer at %zu is not 256-byte aligned", a.first); return -1; }
+        if (a.first < end) { ishara_set_error("workspace buffers overlap at offset %zu (previous buffer ends at %zu)", a.first, end); return -1; }
+        end = a.first + a.second;
+        if (end > m->ws_need) { ishara_set_error("workspace buffer [%zu, %zu) exceeds the planned size %zu", a.first, end, m->ws_need); return -1; }
+    }
+    return (int32_t)m->allocs.size();
+}
+// Guard zones (ISHARA_WS_GUARD=1 at create): synchronises the device, returns 0 when every guard still holds its pattern, else -3
+// with the workspace offset of the first damaged guard (and the buffer in front of it) in ishara_last_error().  0 guards: returns 0.
+extern "C" int ishara_workspace_guard_check(ishara_model* m) {
+    if (!m->guard || !m->ws) return 0;
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    std::vector<uint32_t> got(64);
+    for (size_t gi = 0; gi < m->guard_offs.size(); ++gi) {
+        HIP_CHECK_RET(hipMemcpy(got.data(), m->ws + m->guard_offs[gi], 256, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 64; ++i)
+            if (got[i] != 0xA5C3A5C3u) {
+                size_t boff = 0, bsz = 0;
+                for (auto& a : m->allocs) if (a.first < m->guard_offs[gi] && a.first >= boff) { boff = a.first; bsz = a.second; }
+                ishara_set_error("workspace guard %zu at offset %zu damaged at byte %d (value 0x%08x): the buffer in front of it is [%zu, %zu)",
+                                 gi, m->guard_offs[gi], i * 4, got[i], boff, boff + bsz);
+                return -3;
+            }
+    }
+    return 0;
+}
 
 extern "C" int ishara_bind(ishara_model* m, float* params, float* grads, float* opt_m, float* opt_v, float* opt_slow, void* workspace, int64_t workspace_bytes) {
     if (!params || !workspace) { ishara_set_error("ishara_bind: params and workspace are required"); return -1; }
@@ -365,6 +402,10 @@ extern "C" int ishara_bind(ishara_model* m, float* params, float* grads, float* 
     m->params = params; m->grads = grads; m->om = opt_m; m->ov = opt_v; m->oslow = opt_slow;
     m->ws = (char*)workspace; m->ws_bytes = workspace_bytes;
     m->shadow_ready = false;               // new buffers: rebuild the descriptor table and re-zero the padding
+    if (m->guard) {
+        std::vector<uint32_t> pat(64, 0xA5C3A5C3u);
+        for (size_t off : m->guard_offs) HIP_CHECK_RET(hipMemcpy(m->ws + off, pat.data(), 256, hipMemcpyHostToDevice));
+    }
     if (m->family == ISHARA_FAMILY_KERAS_HYBRID) HIP_CHECK_RET(hipMemcpy(m->ws + m->pe.off, m->pe_host.data(), m->pe_host.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
@@ -376,6 +417,11 @@ extern "C" int ishara_sync_weights(ishara_model* m, ishara_stream st) {
     // weights in one launch (63 launches + a fill of the arena were 0.23 ms of a 21 ms step)
     if (!m->shadow_ready) {
         HIP_CHECK_RET(hipMemsetAsync(m->ws + m->shadow_begin, 0, m->shadow_end - m->shadow_begin, s));
+        if (m->guard) {                          // the arena fill above also cleared the guard zones between the shadows: re-arm them
+            static const std::vector<uint32_t> pat(64, 0xA5C3A5C3u);
+            for (size_t off : m->guard_offs)
+                if (off >= m->shadow_begin && off < m->shadow_end) HIP_CHECK_RET(hipMemcpyAsync(m->ws + off, pat.data(), 256, hipMemcpyHostToDevice, s));
+        }
         std::vector<ShadowDesc> tab;
         int tile0 = 0;
         for (DenseW* w : m->denses) {
@@ -651,7 +697,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
     const int dt = m->dt, d = m->d, T = m->T;
     OpArgs no; EpiArgs e0;
     float* nl = nll ? nll : m->Wf(m->nllb);
-    HIP_CHECK_RET(hipMemsetAsync(m->grads, 0, (size_t)m->n_train * sizeof(float), m->s));
+    CK(launch_fill_u32(m->grads, (size_t)m->n_train, 0u, m->s));      // a kernel, not a memset node: the whole step stays capturable (hipGraph note)
     CKP(m, "ctc", 2.0 * r.M * m->C * 4, 0, launch_ctc(logits, labels, B, T, m->C, m->L, m->C - 1, nl, m->Wf(m->dlogits), loss_scale / (float)B, m->Wf(m->ctcws), m->s, m->cls_pad ? m->W(m->dlb) : nullptr));
     if (loss) CKP(m, "mean", 0, 0, launch_mean(nl, loss, B, 1.f / (float)B, m->s));
     // ---- head

@@ -140,7 +140,16 @@ struct ishara_model {
         return (int)entries.size() - 1;
     }
     size_t cur = 0;
-    Buf alloc(size_t bytes) { Buf b; b.off = cur; cur = rup(cur + bytes, 256); return b; }
+    // ISHARA_WS_GUARD=1 (read at ishara_create): every workspace buffer is followed by a 256-byte guard zone that ishara_bind fills
+    // with a pattern and ishara_workspace_guard_check verifies — an out-of-bounds write of any kernel into a neighbouring buffer
+    // shows up as a named offset instead of as silent corruption (tests/test_tflite_gpu.py, tests/test_model_gpu.py)
+    bool guard = false; std::vector<size_t> guard_offs; std::vector<std::pair<size_t, size_t>> allocs;
+    Buf alloc(size_t bytes) {
+        Buf b; b.off = cur; cur = rup(cur + bytes, 256);
+        allocs.push_back({b.off, bytes});
+        if (guard) { guard_offs.push_back(cur); cur += 256; }
+        return b;
+    }
     Buf act(int cols) { return alloc((size_t)Bmax * T * cols * dt_size(dt)); }
     Buf f32(size_t n) { return alloc(n * sizeof(float)); }
     DenseW dense(const std::string& name, int K, int N, bool bias) {

@@ -84,3 +84,15 @@ def test_product_path_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+@pytest.mark.parametrize("guard", ["0", "1"])
+def test_workspace_plan_has_no_overlap(guard, monkeypatch):
+    """Host-side audit of the bump-allocated workspace: aligned, in bounds, disjoint — with and without guard zones."""
+    monkeypatch.setenv("ISHARA_WS_GUARD", guard)
+    for kw in (dict(dim=64, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, max_batch=1, dtype="f32"),
+               dict(dim=256, input_shape=(384, 224), max_batch=256),
+               dict(dim=512, num_conv_squeeze_blocks=6, num_conv_conform_blocks=6, input_shape=(512, 224), max_batch=8)):
+        m = Model(make_config(**kw), device=None)
+        n = m._lib.ishara_workspace_plan_check(m._h)
+        assert n > 100, _lib.load().ishara_last_error()

@@ -86,6 +86,14 @@ BF16_TOL = dict(logits=0.15, loss=2e-2, grad=0.12, grad_small=0.2, stats=3e-2)
 
 
 def check_train_step(kw, dtype, dropout, tag, bf16_tol=BF16_TOL, check_decode=False):
+    os.environ["ISHARA_WS_GUARD"] = "1"       # guard zones behind every workspace buffer (read at ishara_create), verified below
+    try:
+        _check_train_step(kw, dtype, dropout, tag, bf16_tol, check_decode)
+    finally:
+        os.environ.pop("ISHARA_WS_GUARD", None)
+
+
+def _check_train_step(kw, dtype, dropout, tag, bf16_tol, check_decode):
     """One training step (forward, CTC, backward) of the HIP library vs the fp64 oracle on the same weights, batch and
     dropout seed: logits, loss, every parameter gradient, the BatchNorm moving statistics."""
     from oracle import ishara_oracle as O
@@ -99,6 +107,8 @@ def check_train_step(kw, dtype, dropout, tag, bf16_tol=BF16_TOL, check_decode=Fa
     loss, logits = float(loss_t.item()), logits_t.cpu().numpy()
     grads = model.get_gradients()
     W_after = model.get_weights()
+    from ishara_amd import _lib
+    _lib.check(model._lib.ishara_workspace_guard_check(model._h), "workspace guard (a kernel wrote outside its buffer)")
     ref_loss, ref_logits, ref_grads, ref_stats = O.loss_and_grads(W, x, y, ocfg, training=True, seed=seed, dtype=torch.float64)
     lerr = float(np.abs(logits - ref_logits).max())
     bad, gmax, gmax_name = [], 0.0, ""

@@ -52,11 +52,13 @@ def test_preprocess_kernel_matches_oracle(lib, n):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_tflite_wrapper_end_to_end(use_graph):
+def test_tflite_wrapper_end_to_end(use_graph, monkeypatch):
     from oracle import ishara_oracle as O
     from oracle import preprocess_oracle as PO
     kw = dict(dim=64, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, input_shape=(176, 276))
+    monkeypatch.setenv("ISHARA_WS_GUARD", "1")       # guard zones between all workspace buffers, checked once at the end
     model = get_model(**kw, dtype="f32", max_batch=1, seed=5)
+    assert model._lib.ishara_workspace_plan_check(model._h) > 0
     stats = _stats()
     tfl = TFLiteModel(model, stats=stats, max_frames=512, use_graph=use_graph)
     ocfg = O.Config(**kw)
@@ -74,3 +76,5 @@ def test_tflite_wrapper_end_to_end(use_graph):
         if (top2[:, 1] - top2[:, 0]).min() > 1e-3:            # no near-tie frame: identical indices
             assert out.shape == want.shape and np.array_equal(out, want), f"n={n}"
         assert np.abs(tfl._logits[0].cpu().numpy() - lg).max() <= 1e-4
+    # no kernel of the forward pass (eager or replayed from the hipGraph) wrote outside its workspace buffer
+    _lib.check(model._lib.ishara_workspace_guard_check(model._h), "workspace guard")
