@@ -174,7 +174,7 @@ void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_
 void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s, int nb = 0, int nbv = 0);
 bool dwconv_bwd_fused_ok(int dt, int C, int k, int padl);
 int launch_dwconv_bwd_fused(int dt, int inop, const void* dy, const void* x, const float* w, void* dx, float* part,
-                            int B, int T, int C, int k, int padl, int max_rows, hipStream_t s);
+                            int B, int T, int C, int k, int padl, int max_rows, hipStream_t s, const DwBnArgs& bn);
 
 int launch_layernorm_bwd(int dt, const void* dy, const void* x, const float* mean, const float* rstd,
                          const float* gamma, const void* resid, void* dx, float* dgamma, float* dbeta,
@@ -831,12 +831,23 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     }
 }
 
+int launch_dwconv_bwd_bn(int dt, int inop, const void* dy, const DwBnArgs& bn, const void* x, const float* w, void* dx,
+                         float* dw, float* dbias, float* scratch, int B, int T, int C, int k, int padl, hipStream_t s) {
+    if (dwconv_check(C, k)) return -1;
+    if (!bn.h || !scratch || g_force_dw_lds || !dwconv_bwd_fused_ok(dt, C, k, padl) || k >= 15) return 0;      // k = 15: the 15-row window + the BatchNorm coefficients spill (26+ VGPRs)
+    const int rows = launch_dwconv_bwd_fused(dt, inop, dy, x, w, dx, scratch, B, T, C, k, padl, DWG_BLOCKS, s, bn);
+    if (rows < 0) return -2;
+    launch_reduce_slabs(scratch, dw, k * C, rows, (size_t)(k + 1) * C, s);
+    if (dbias) launch_reduce_slabs(scratch + (size_t)k * C, dbias, C, rows, (size_t)(k + 1) * C, s);
+    return hipGetLastError() == hipSuccess ? 1 : -2;
+}
+
 int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const float* w, void* dx,
                       float* dw, float* dbias, float* scratch, int B, int T, int C, int k, int padl, hipStream_t s) {
     if (dwconv_check(C, k)) return -1;
     if (scratch && !g_force_dw_lds && dwconv_bwd_fused_ok(dt, C, k, padl)) {
         // one pass: dx and the per-workgroup partial rows of (dw, dbias), then the row sum
-        const int rows = launch_dwconv_bwd_fused(dt, inop, dy, x, w, dx, scratch, B, T, C, k, padl, DWG_BLOCKS, s);
+        const int rows = launch_dwconv_bwd_fused(dt, inop, dy, x, w, dx, scratch, B, T, C, k, padl, DWG_BLOCKS, s, DwBnArgs());
         if (rows < 0) return -2;
         launch_reduce_slabs(scratch, dw, k * C, rows, (size_t)(k + 1) * C, s);
         if (dbias) launch_reduce_slabs(scratch + (size_t)k * C, dbias, C, rows, (size_t)(k + 1) * C, s);

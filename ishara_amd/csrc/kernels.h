@@ -85,6 +85,15 @@ size_t dwconv_fwd_scratch_floats(int B, int T, int C);
 // dx = d in(x) ; dw [k,C], dbias [C] accumulated (through `scratch` partial rows of
 // dwconv_bwd_scratch_floats(C,k) floats when given, else atomically).
 size_t dwconv_bwd_scratch_floats(int C, int k);
+// BatchNorm backward folded into the depthwise-conv backward: dy is the gradient of BN(y), h = y (the conv's forward output, [B,T,C]);
+// the kernel applies dy <- a[c] * (dy*sg[b,c] + E[b or 0,c] - xhat*Fc[c]) (the arithmetic of launch_bn_bwd_apply) to each dy row as it
+// loads it.  h == nullptr: plain depthwise-conv backward.
+struct DwBnArgs { const void* h = nullptr; const float* mean = nullptr; const float* rstd = nullptr; const float* a = nullptr;
+                  const float* sg = nullptr; const float* E = nullptr; const float* Fc = nullptr; int e_per_sample = 0; };
+// returns 1 when the fused one-pass kernel took the call (dx, dw, dbias written), 0 when this shape has no fused kernel (the caller
+// runs launch_bn_bwd_apply + launch_dwconv_bwd instead), < 0 on error
+int launch_dwconv_bwd_bn(int dt, int inop, const void* dy, const DwBnArgs& bn, const void* x, const float* w, void* dx,
+                         float* dw, float* dbias, float* scratch, int B, int T, int C, int k, int padl, hipStream_t s);
 int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const float* w, void* dx,
                       float* dw, float* dbias, float* scratch, int B, int T, int C, int k, int padl, hipStream_t s);
 

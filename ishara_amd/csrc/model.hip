@@ -604,8 +604,15 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
     CKP(m, "eca_bn_bwd_finalize", 0, 0, launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
                                   m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), m->Wf(m->ecap), B, T, c, m->s));
-    CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.sg), m->Wf(m->E), 1, m->Wf(m->Fc), m->W(m->t1), B, T, c, m->s));
-    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s));
+    // BatchNorm backward applied inside the depthwise-conv backward (one pass over dh4, h2 and z1); shapes without the fused kernel
+    // take the two-kernel path
+    DwBnArgs bn; bn.h = m->W(cb.h2); bn.mean = m->Wf(cb.mean); bn.rstd = m->Wf(cb.rstd); bn.a = m->Wf(cb.a); bn.sg = m->Wf(cb.sg); bn.E = m->Wf(m->E); bn.Fc = m->Wf(m->Fc); bn.e_per_sample = 1;
+    int fused = 0;
+    CKP(m, "dwconv_bwd", 10.0 * r.M * m->d * (double)dt_size(m->dt), 0, (fused = launch_dwconv_bwd_bn(dt, DWIN_SWISH, m->W(m->t1), bn, m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s)) < 0 ? fused : 0);
+    if (!fused) {
+        CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.sg), m->Wf(m->E), 1, m->Wf(m->Fc), m->W(m->t1), B, T, c, m->s));
+        CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s));
+    }
     EpiArgs e2; e2.resid = g;
     CK(gemm_dgrad(m, cb.W1, m->W(m->t2), dt, gn, r.M, OP_NONE, no, e2));
     CK(gemm_wgrad(m, cb.W1, x, dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
@@ -680,8 +687,13 @@ int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, cons
     CK(gemm_wgrad(m, c.Wp2, m->W(c.bnv), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
     CKP(m, "bn_bwd_finalize", 0, 0, launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(c.bn.gamma), m->G(c.bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
-    CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv
-    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
+    DwBnArgs bn; bn.h = m->W(c.v); bn.mean = m->Wf(c.mean); bn.rstd = m->Wf(c.rstd); bn.a = m->Wf(c.a); bn.E = m->Wf(m->Ecol); bn.Fc = m->Wf(m->Fc);
+    int fused = 0;
+    CKP(m, "dwconv_bwd", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, (fused = launch_dwconv_bwd_bn(dt, DWIN_GLU, m->W(m->t2), bn, m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s)) < 0 ? fused : 0);   // dg [M,2d]
+    if (!fused) {
+        CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv
+        CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
+    }
     EpiArgs e2; e2.resid = m->W(m->t1);
     CK(gemm_dgrad(m, c.Wp1, m->W(m->t3), dt, gn, r.M, OP_NONE, no, e2));
     CK(gemm_wgrad(m, c.Wp1, x, dt, OP_NONE, no, m->W(m->t3), dt, OP_NONE, no, r.M));
