@@ -22,7 +22,9 @@ extern "C" {
 typedef struct ishara_model ishara_model;
 typedef void* ishara_stream;              /* hipStream_t */
 
-enum { ISHARA_F32 = 0, ISHARA_BF16 = 1 };
+/* activation storage + MFMA input type.  ISHARA_F16: inference only (the fp16 TFLite export of c14:1-5; ishara_forward(training=1)
+ * is refused) — weights and activations in fp16, fp16 MFMA with fp32 accumulation, fp32 statistics / softmax / logits. */
+enum { ISHARA_F32 = 0, ISHARA_BF16 = 1, ISHARA_F16 = 2 };
 /* model families behind one handle type: the Keras hybrid of get_model (conv-hybrid-model.ipynb c7:1-72) and the torch
  * ConformerEncoder of conformer/conformer.py:76-87 (post-LN blocks, encoder stack only) */
 enum { ISHARA_FAMILY_KERAS_HYBRID = 0, ISHARA_FAMILY_TORCH_CONFORMER = 1 };
@@ -49,7 +51,7 @@ typedef struct ishara_config {
     int32_t conformer_expansion;    /* 0 -> expansion_factor */
     float   head_dropout;           /* c7:62: 0.4 */
     float   conformer_attn_dropout; /* c5:312 default 0.1 */
-    int32_t dtype;                  /* ISHARA_F32 | ISHARA_BF16: activation storage + MFMA input type */
+    int32_t dtype;                  /* ISHARA_F32 | ISHARA_BF16 | ISHARA_F16 (inference only): activation storage + MFMA input type */
     int32_t max_batch;              /* workspace is planned for this many clips */
     int32_t max_label_len;          /* MAX_PHRASE_LENGTH = 64 (c1:28) */
     int32_t attn_impl;              /* 0 lane-split VALU, 1 MFMA (bf16 only) */

@@ -5,6 +5,8 @@
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef _Float16 f16;                                      // inference-only storage type (BASELINE configs[4]: fp16 B=1 decode)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -16,9 +18,15 @@ template <> struct is_bf16_t<bf16> { static constexpr bool value = true; };
 
 DEVI float to_f(float v) { return v; }
 DEVI float to_f(bf16 v) { return (float)v; }
+DEVI float to_f(f16 v) { return (float)v; }
+// 16-bit storage types (8 elements per 16-byte chunk)
+template <typename T> struct is_16b_t { static constexpr bool value = false; };
+template <> struct is_16b_t<bf16> { static constexpr bool value = true; };
+template <> struct is_16b_t<f16> { static constexpr bool value = true; };
 template <typename T> DEVI T from_f(float v);
 template <> DEVI float from_f<float>(float v) { return v; }
 template <> DEVI bf16 from_f<bf16>(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+template <> DEVI f16 from_f<f16>(float v) { return (f16)v; }
 
 // ---- 8-element vector IO (16 B for bf16, 2x16 B for f32) -------------------
 DEVI void load8(const float* p, float (&v)[8]) {
@@ -30,6 +38,17 @@ DEVI void load8(const bf16* p, float (&v)[8]) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+DEVI void load8(const f16* p, float (&v)[8]) {
+    const f16x8 a = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+DEVI void store8(f16* p, const float (&v)[8]) {
+    f16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (f16)v[i];
+    *reinterpret_cast<f16x8*>(p) = a;
 }
 DEVI void store8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -62,6 +81,19 @@ DEVI void load4g(const bf16* p, float (&v)[4]) {
     const uint2 u = *reinterpret_cast<const uint2*>(p);
     v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xFFFF0000u);
     v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+}
+DEVI void load4g(const f16* p, float (&v)[4]) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    const f16x4 a = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+}
+DEVI void store4(f16* p, const float (&v)[4]) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    f16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (f16)v[i];
+    *reinterpret_cast<f16x4*>(p) = a;
 }
 DEVI void store4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 DEVI void store4(bf16* p, const float (&v)[4]) {

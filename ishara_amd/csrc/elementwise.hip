@@ -87,7 +87,7 @@ int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float*
 #define LN_F(TT, GG) hipLaunchKernelGGL((layernorm_fwd_kernel<TT, GG>), dim3(grid), dim3(256), 0, s, (const TT*)x, gamma, beta, eps, (TT*)y, mean, rstd, M, C)
 #define LN_FG(TT) switch (G) { case 1: LN_F(TT, 1); break; case 2: LN_F(TT, 2); break; case 4: LN_F(TT, 4); break; case 8: LN_F(TT, 8); break; \
                                case 16: LN_F(TT, 16); break; case 32: LN_F(TT, 32); break; default: LN_F(TT, 64); break; }
-    if (dt == DT_BF16) { LN_FG(bf16) } else { LN_FG(float) }
+    if (dt == DT_BF16) { LN_FG(bf16) } else if (dt == DT_F16) { LN_FG(f16) } else { LN_FG(float) }
     return LAUNCH_OK();
 }
 
@@ -701,11 +701,13 @@ int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const flo
         const int nseg = (T + DWR_SEG - 1) / DWR_SEG;
         P = (nseg + 3) / 4;
         if (dt == DT_BF16) launch_dw_reg<bf16>(k, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s, part);
+        else if (dt == DT_F16) launch_dw_reg<f16>(k, (const f16*)x, w, bias, (f16*)y, (const f16*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s, part);
         else launch_dw_reg<float>(k, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s, part);
     } else {
         dim3 grid((T + DW_TT - 1) / DW_TT, (C + DW_CT - 1) / DW_CT, B);
         P = grid.x;
         if (dt == DT_BF16) DWK_LAUNCH(bf16, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0, part);
+        else if (dt == DT_F16) DWK_LAUNCH(f16, (const f16*)x, w, bias, (f16*)y, (const f16*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0, part);
         else DWK_LAUNCH(float, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0, part);
     }
     if (part) hipLaunchKernelGGL(stats_reduce_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, P, colsum, colsq, B, C);
@@ -948,6 +950,7 @@ int launch_sample_reduce(int dt, const void* dy, const void* other, const float*
     if (C % 8 != 0) { ishara_set_error("sample_reduce: C%%8 != 0"); return -1; }
     dim3 grid(B, (C + 127) / 128);
     if (dt == DT_BF16) hipLaunchKernelGGL(sample_reduce_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dy, (const bf16*)other, mean, rstd, S1, S2, B, T, C);
+    else if (dt == DT_F16) hipLaunchKernelGGL(sample_reduce_kernel<f16>, grid, dim3(256), 0, s, (const f16*)dy, (const f16*)other, mean, rstd, S1, S2, B, T, C);
     else hipLaunchKernelGGL(sample_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)other, mean, rstd, S1, S2, B, T, C);
     return LAUNCH_OK();
 }
@@ -1083,6 +1086,7 @@ static int run_affine(int dt, const void* x, const float* P, const float* Q, con
     if (gx > cap) gx = cap;
     dim3 grid(gx, B);
     if (dt == DT_BF16) hipLaunchKernelGGL(affine_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, P, Q, (const bf16*)resid, (bf16*)y, T, C, per_sample);
+    else if (dt == DT_F16) hipLaunchKernelGGL(affine_kernel<f16>, grid, dim3(256), 0, s, (const f16*)x, P, Q, (const f16*)resid, (f16*)y, T, C, per_sample);
     else hipLaunchKernelGGL(affine_kernel<float>, grid, dim3(256), 0, s, (const float*)x, P, Q, (const float*)resid, (float*)y, T, C, per_sample);
     return LAUNCH_OK();
 }
@@ -1430,6 +1434,7 @@ int launch_map_rows(int dt, int op, const void* x, void* y, const float* rs, Dro
     const int cpr = min(C / 8, 256), rpb = 256 / cpr;
     const int grid = max(1, min((M + rpb - 1) / rpb, 4096));
     if (dt == DT_BF16) hipLaunchKernelGGL(map_rows_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, op, rs, drop, M, T, C);
+    else if (dt == DT_F16) hipLaunchKernelGGL(map_rows_kernel<f16>, dim3(grid), dim3(256), 0, s, (const f16*)x, (f16*)y, op, rs, drop, M, T, C);
     else hipLaunchKernelGGL(map_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, op, rs, drop, M, T, C);
     return LAUNCH_OK();
 }

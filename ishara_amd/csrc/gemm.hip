@@ -14,6 +14,7 @@
 // the fused epilogue (bias, PE table, activation, dropout, drop-path, act', residual,
 // QKV head split with V transposed) runs on whole 8-element row chunks with 16-byte
 // coalesced global accesses.
+#include <type_traits>
 #include "kernels.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -21,6 +22,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 template <typename TM> struct MmaCfg;
 template <> struct MmaCfg<bf16>  { static constexpr int EPC = 8; static constexpr int BK = 64; };
+template <> struct MmaCfg<f16>   { static constexpr int EPC = 8; static constexpr int BK = 64; };
 template <> struct MmaCfg<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };
 
 // ---------------------------------------------------------------------------------
@@ -65,7 +67,7 @@ DEVI void load_row_chunk(const T* __restrict__ base, int ld, int rows, int cols,
     for (int e = 0; e < N; ++e) v[e] = 0.f;
     if (row >= rows) return;
     const T* p = base + (size_t)row * ld + col;
-    if constexpr (is_bf16_t<T>::value) {
+    if constexpr (is_16b_t<T>::value) {
         if (col + N <= cols) {
             if constexpr (N == 8) load8(p, v);
             else load4g(p, v);
@@ -86,9 +88,17 @@ DEVI uint32_t pack_bf16x2(float lo, float hi) {
     bf16x2 t; t[0] = (bf16)lo; t[1] = (bf16)hi;
     return __builtin_bit_cast(uint32_t, t);
 }
+DEVI uint32_t pack_f16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    f16x2 t; t[0] = (f16)lo; t[1] = (f16)hi;
+    return __builtin_bit_cast(uint32_t, t);
+}
 template <typename TM, int N> DEVI u32x4 pack_chunk(const float (&v)[N]) {
     u32x4 r;
-    if constexpr (is_bf16_t<TM>::value) {
+    if constexpr (std::is_same<TM, f16>::value) {
+        r.x = pack_f16x2(v[0], v[1]); r.y = pack_f16x2(v[2], v[3]);
+        r.z = pack_f16x2(v[4], v[5]); r.w = pack_f16x2(v[6], v[7]);
+    } else if constexpr (is_bf16_t<TM>::value) {
         r.x = pack_bf16x2(v[0], v[1]); r.y = pack_bf16x2(v[2], v[3]);
         r.z = pack_bf16x2(v[4], v[5]); r.w = pack_bf16x2(v[6], v[7]);
     } else {
@@ -107,7 +117,27 @@ template <int SW> DEVI int swz(int row) { return SW == 0 ? (row & 7) : ((row ^ (
 template <typename TM, int SW>
 DEVI void mma_tile(const char* ldsA, const char* ldsB, int wr, int wc, int lane, f32x4 (&acc)[4][4]) {
     const int r = lane & 15, g = lane >> 4;
-    if constexpr (is_bf16_t<TM>::value) {
+    if constexpr (std::is_same<TM, f16>::value) {      // same tile layout as bf16, the f16 MFMA
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wr * 64 + 16 * i + r;
+                a[i] = *reinterpret_cast<const f16x8*>(ldsA + row * 128 + (((4 * s + g) ^ swz<SW>(row)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wc * 64 + 16 * j + r;
+                b[j] = *reinterpret_cast<const f16x8*>(ldsB + row * 128 + (((4 * s + g) ^ swz<SW>(row)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    } else if constexpr (is_bf16_t<TM>::value) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 a[4], b[4];
@@ -923,11 +953,18 @@ int g_dbg_tn = 0;           // ablation bits for the TN kernel: 1 skip MFMA, 2 s
 int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
                    int M, int N, int K, int ldb, const OpArgs& oa, const EpiArgs& ea, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) { ishara_set_error("gemm_nt: bad shape %d %d %d", M, N, K); return -1; }
-    if ((dtA == DT_BF16 && K % 8 != 0) || (dtA == DT_F32 && K % 4 != 0) || ((uintptr_t)A) % 16 != 0) {
+    if ((dt_is16(dtA) && K % 8 != 0) || (dtA == DT_F32 && K % 4 != 0) || ((uintptr_t)A) % 16 != 0) {
         ishara_set_error("gemm_nt: A rows must be 16-byte aligned (K=%d)", K); return -1;
     }
     if (ea.mode == EPI_QKV && (ea.T % 8 != 0 || N % 8 != 0 || ea.dh % 8 != 0)) {
         ishara_set_error("gemm_nt: QKV split needs T, dh multiples of 8 (T=%d dh=%d)", ea.T, ea.dh); return -1;
+    }
+    if (dtM == DT_F16) {          // inference-only storage type: the register-staged 128x128 tile kernel with the f16 MFMA
+        if (op != OP_NONE) { ishara_set_error("gemm_nt: f16 operands take no operand transform"); return -1; }
+        if (dtA == DT_F16 && dtC == DT_F16) return run_nt<f16, f16, f16, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+        if (dtA == DT_F32 && dtC == DT_F16) return run_nt<float, f16, f16, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+        if (dtA == DT_F16 && dtC == DT_F32) return run_nt<f16, f16, float, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
+        ishara_set_error("gemm_nt: unsupported f16 dtype combination %d/%d/%d", dtA, dtM, dtC); return -1;
     }
     const int bk = dtM == DT_BF16 ? 32 : 16;     // K tile of the LDS-DMA kernel
     const bool dma_ok = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0;
@@ -1598,6 +1635,7 @@ __global__ void make_shadow_batched_kernel(const ShadowDesc* __restrict__ tab, i
 int launch_make_shadow_batched(int dtM, const ShadowDesc* tab, int ntab, int total_tiles, hipStream_t s) {
     if (ntab <= 0 || total_tiles <= 0) return 0;
     if (dtM == DT_BF16) hipLaunchKernelGGL(make_shadow_batched_kernel<bf16>, dim3(total_tiles), dim3(256), 0, s, tab, ntab);
+    else if (dtM == DT_F16) hipLaunchKernelGGL(make_shadow_batched_kernel<f16>, dim3(total_tiles), dim3(256), 0, s, tab, ntab);
     else hipLaunchKernelGGL(make_shadow_batched_kernel<float>, dim3(total_tiles), dim3(256), 0, s, tab, ntab);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -1605,6 +1643,7 @@ int launch_make_shadow_batched(int dtM, const ShadowDesc* tab, int ntab, int tot
 int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt, void* Wn, int ldn, hipStream_t s) {
     dim3 grid((N + 31) / 32, (K + 31) / 32);
     if (dtM == DT_BF16) hipLaunchKernelGGL(make_shadow_kernel<bf16>, grid, dim3(256), 0, s, W, K, N, (bf16*)Wt, ldt, (bf16*)Wn, ldn);
+    else if (dtM == DT_F16) hipLaunchKernelGGL(make_shadow_kernel<f16>, grid, dim3(256), 0, s, W, K, N, (f16*)Wt, ldt, (f16*)Wn, ldn);
     else hipLaunchKernelGGL(make_shadow_kernel<float>, grid, dim3(256), 0, s, W, K, N, (float*)Wt, ldt, (float*)Wn, ldn);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -1631,6 +1670,7 @@ int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStr
 }
 
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea) {
+    if (dtM == DT_F16) return "gemm_nt_kernel<f16>";
     const int bk = dtM == DT_BF16 ? 32 : 16;
     const bool dma = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0;
     if (dma && g_force_regstage == 0 && dtM == DT_BF16 && gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return gemm_nt_as_name(dtC, K, ea);

@@ -3,8 +3,9 @@
 #pragma once
 #include "common.h"
 
-enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };       // DT_F16: forward (inference) kernels only
 static inline size_t dt_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+static inline bool dt_is16(int dt) { return dt != DT_F32; }
 
 // ---- operand transforms applied while staging a GEMM operand -------------------
 enum : int { OP_NONE = 0, OP_SWISH = 1, OP_COLAFFINE = 2, OP_ROWSCALE = 3, OP_DROPMASK = 4 };

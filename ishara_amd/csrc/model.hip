@@ -192,7 +192,7 @@ static void build_graph(ishara_model* m) {
 }
 
 void plan_shadow(ishara_model* m, DenseW& w, int min_ldt, int min_ldn) {
-    const int bk = m->dt == DT_BF16 ? 64 : 32;
+    const int bk = dt_is16(m->dt) ? 64 : 32;
     const size_t es = dt_size(m->dt);
     w.ldt = (int)rup(w.K, bk);
     if (w.ldt < min_ldt) w.ldt = min_ldt;      // zero-padded K (the shadow arena is zero-filled, the builder writes k < K)
@@ -314,13 +314,14 @@ extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     for (int i = 0; i < c.num_kernel_sizes; ++i) if (c.kernel_sizes[i] < 1 || c.kernel_sizes[i] > 31) { ishara_set_error("kernel size %d unsupported (1..31)", c.kernel_sizes[i]); return -1; }
     if (c.transformer_kernel_size < 1 || c.transformer_kernel_size > 31 || c.transformer_kernel_size % 2 == 0) { ishara_set_error("transformer_kernel_size must be odd, 1..31"); return -1; }
     if (c.max_batch <= 0) { ishara_set_error("max_batch must be > 0"); return -1; }
-    if (c.dtype != ISHARA_F32 && c.dtype != ISHARA_BF16) { ishara_set_error("dtype must be ISHARA_F32 or ISHARA_BF16"); return -1; }
+    if (c.dtype != ISHARA_F32 && c.dtype != ISHARA_BF16 && c.dtype != ISHARA_F16) { ishara_set_error("dtype must be ISHARA_F32, ISHARA_BF16 or ISHARA_F16"); return -1; }
+    if (c.dtype == ISHARA_F16 && c.family != ISHARA_FAMILY_KERAS_HYBRID) { ishara_set_error("ISHARA_F16 (inference-only storage) exists for the Keras hybrid family only"); return -1; }
     if (c.top_dim <= 0) c.top_dim = 2 * c.dim;
     if (c.top_dim % 8 != 0) { ishara_set_error("top_dim must be a multiple of 8"); return -1; }
     if (c.max_label_len <= 0) c.max_label_len = 64;
     if (c.max_label_len > 255) { ishara_set_error("max_label_len > 255"); return -1; }
     ishara_model* m = new ishara_model();
-    m->cfg = c; m->dt = c.dtype == ISHARA_BF16 ? DT_BF16 : DT_F32;
+    m->cfg = c; m->dt = c.dtype == ISHARA_BF16 ? DT_BF16 : (c.dtype == ISHARA_F16 ? DT_F16 : DT_F32);
     m->d = c.dim; m->T = c.frames; m->F = c.features; m->C = c.num_classes; m->H = c.num_heads; m->dh = dh;
     m->dtop = c.top_dim; m->Bmax = c.max_batch; m->L = c.max_label_len;
     m->family = c.family;
@@ -545,6 +546,10 @@ extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float*
     if (!m->ws) { ishara_set_error("ishara_forward: model is not bound"); return -1; }
     if (m->family != ISHARA_FAMILY_KERAS_HYBRID) { ishara_set_error("ishara_forward: this handle is an encoder-only family; use ishara_encoder_forward"); return -1; }
     if (B <= 0 || B > m->Bmax) { ishara_set_error("ishara_forward: batch %d outside 1..%d", B, m->Bmax); return -1; }
+    if (m->dt == DT_F16 && training) {
+        ishara_set_error("ishara_forward: ISHARA_F16 is an inference-only storage type (the reference's fp16 is the TFLite export, c14:1-5; it reports NaNs when TRAINING in fp16)");
+        return -1;
+    }
     m->s = (hipStream_t)st;
     Run r{B, B * m->T, training, seed};
     const int dt = m->dt, d = m->d, T = m->T;

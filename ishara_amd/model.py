@@ -427,7 +427,8 @@ def make_config(dim=256, num_conv_squeeze_blocks=2, num_conv_conform_blocks=2, k
     c.frames, c.features, c.num_classes = input_shape[0], input_shape[1], num_classes
     c.top_dim, c.squeeze_expansion, c.conformer_expansion = top_dim, squeeze_expansion, conformer_expansion
     c.head_dropout, c.conformer_attn_dropout = head_dropout, conformer_attn_dropout
-    c.dtype = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16}[dtype]
+    c.dtype = {"f32": _lib.F32, "fp32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16,
+               "f16": _lib.F16, "fp16": _lib.F16, "float16": _lib.F16}[dtype]
     c.max_batch, c.max_label_len, c.attn_impl = max_batch, max_label_len, attn_impl
     return c
 
