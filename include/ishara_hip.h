@@ -25,9 +25,10 @@ typedef void* ishara_stream;              /* hipStream_t */
 /* activation storage + MFMA input type.  ISHARA_F16: inference only (the fp16 TFLite export of c14:1-5; ishara_forward(training=1)
  * is refused) — weights and activations in fp16, fp16 MFMA with fp32 accumulation, fp32 statistics / softmax / logits. */
 enum { ISHARA_F32 = 0, ISHARA_BF16 = 1, ISHARA_F16 = 2 };
-/* model families behind one handle type: the Keras hybrid of get_model (conv-hybrid-model.ipynb c7:1-72) and the torch
- * ConformerEncoder of conformer/conformer.py:76-87 (post-LN blocks, encoder stack only) */
-enum { ISHARA_FAMILY_KERAS_HYBRID = 0, ISHARA_FAMILY_TORCH_CONFORMER = 1 };
+/* model families behind one handle type: the Keras hybrid of get_model (conv-hybrid-model.ipynb c7:1-72), the torch
+ * ConformerEncoder of conformer/conformer.py:76-87 (post-LN blocks, encoder stack only) and the torch SqueezeformerEncoder of
+ * squeezeformer/encoder.py:26-166 (conv2d subsampling, relative-position MHSA, time reduction / recovery) */
+enum { ISHARA_FAMILY_KERAS_HYBRID = 0, ISHARA_FAMILY_TORCH_CONFORMER = 1, ISHARA_FAMILY_TORCH_SQUEEZEFORMER = 2 };
 
 /* get_model(...) kwargs — conv-hybrid-model.ipynb c7:1-11 — plus the notebook globals the
  * function closes over (INPUT_SHAPE c3:119, len(char_to_num) c1:7) and the variant knobs
@@ -57,6 +58,12 @@ typedef struct ishara_config {
     int32_t attn_impl;              /* 0 lane-split VALU, 1 MFMA (bf16 only) */
     int32_t family;                 /* ISHARA_FAMILY_*.  TORCH_CONFORMER reads: dim, num_conv_conform_blocks (= num_layers), num_heads,
                                      * expansion_factor, transformer_kernel_size (= kernel_size, odd), dropout_rate, frames, dtype, max_batch */
+    /* ISHARA_FAMILY_TORCH_SQUEEZEFORMER (encoder.py:54-69) reads: features (= input_dim), dim (= encoder_dim), num_conv_conform_blocks
+     * (= num_layers), num_heads, expansion_factor (= feed_forward_expansion_factor), transformer_kernel_size (= conv_kernel_size),
+     * dropout_rate (all five dropout probabilities), frames (input frames, any count >= 7), dtype, max_batch and: */
+    int32_t reduce_layer_index;     /* >= num_layers: no time reduction */
+    int32_t recover_layer_index;    /* >= num_layers: no recovery */
+    int32_t half_step_residual;     /* 0 | 1 */
 } ishara_config;
 
 const char* ishara_last_error(void);
@@ -101,6 +108,9 @@ int ishara_loss_backward(ishara_model* m, const float* logits, const int64_t* la
  * training=1: Dropout active (seed), BatchNorm1d uses batch statistics and updates running_mean / running_var, the
  * activations the backward pass needs stay in the workspace. */
 int ishara_encoder_forward(ishara_model* m, const float* x, int32_t B, float* y, int32_t training, uint32_t seed, ishara_stream s);
+/* frames per clip of y: `frames` for the ConformerEncoder; ((T-3)/2+1-3)/2+1, then (.-3)/2+1 after the reduction layer and twice
+ * that after the recovery layer for the SqueezeformerEncoder (x is [B, frames, features] there) */
+int32_t ishara_encoder_output_frames(const ishara_model* m);
 /* loss.backward() through the encoder (conformer.py:99-103): dy [B,T,dim] f32 = dLoss/dy of the last ishara_encoder_forward(training=1);
  * parameter gradients fill grads[0,trainable) (overwritten); dx [B,T,dim] f32 may be NULL. */
 int ishara_encoder_backward(ishara_model* m, const float* dy, int32_t B, float* dx, ishara_stream s);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libishara_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-FAMILY_KERAS_HYBRID, FAMILY_TORCH_CONFORMER = 0, 1
+FAMILY_KERAS_HYBRID, FAMILY_TORCH_CONFORMER, FAMILY_TORCH_SQUEEZEFORMER = 0, 1, 2
 
 
 class IsharaError(RuntimeError):
@@ -28,7 +28,7 @@ class Config(C.Structure):
         ("num_classes", C.c_int32), ("top_dim", C.c_int32), ("squeeze_expansion", C.c_int32),
         ("conformer_expansion", C.c_int32), ("head_dropout", C.c_float), ("conformer_attn_dropout", C.c_float),
         ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_label_len", C.c_int32), ("attn_impl", C.c_int32),
-        ("family", C.c_int32),
+        ("family", C.c_int32), ("reduce_layer_index", C.c_int32), ("recover_layer_index", C.c_int32), ("half_step_residual", C.c_int32),
     ]
 
 
@@ -54,6 +54,7 @@ SIGNATURES = {
     "ishara_forward": (C.c_int, [_P, _P, _I32, _P, _I32, _U32, _P]),
     "ishara_encoder_forward": (C.c_int, [_P, _P, _I32, _P, _I32, _U32, _P]),
     "ishara_encoder_backward": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "ishara_encoder_output_frames": (_I32, [_P]),
     "ishara_loss_backward": (C.c_int, [_P, _P, _P, _I32, _P, _P, _F, _P]),
     "ishara_optimizer_step": (C.c_int, [_P, _F, _F, _P]),
     "ishara_optimizer_iterations": (_I32, [_P]),

@@ -97,25 +97,15 @@ class _EncoderFn(torch.autograd.Function):
         return dx, enc.grads[:enc.n_train].clone(), None
 
 
-class ConformerEncoder:
-    """conformer/conformer.py:76-87 on MI355X.  Extra keyword arguments size the device buffers: `seq_len` (frames per clip,
-    a multiple of 8, <= 512), `max_batch`, `dtype` ("bf16" storage + bf16 MFMA with fp32 accumulation, or "f32")."""
+class _TorchFamilyEncoder:
+    """Shared host side of the two torch encoder families: one library handle, flat parameter / gradient buffers, state_dict in
+    the reference's keys and layouts, torch.autograd integration.  Subclasses fill an `_lib.Config` and a layout map."""
 
-    def __init__(self, dim, num_layers=7, num_heads=8, expansion_factor=4, kernel_size=31, dropout=0.1, *,
-                 seq_len=384, max_batch=64, dtype="bf16", device: Optional[str] = "cuda:0", seed=0):
-        if kernel_size % 2 == 0:
-            raise ValueError("kernel_size must be odd (padding=kernel_size//2 keeps the sequence length only then)")
+    def _create(self, cfg, layout_map, in_features, seq_len, max_batch, device, seed):
         self._lib = _lib.load()
-        cfg = _lib.Config()
-        cfg.family = _lib.FAMILY_TORCH_CONFORMER
-        cfg.dim, cfg.num_conv_conform_blocks, cfg.num_heads = dim, num_layers, num_heads
-        cfg.expansion_factor, cfg.transformer_kernel_size, cfg.dropout_rate = expansion_factor, kernel_size, dropout
-        cfg.frames, cfg.features, cfg.num_classes = seq_len, dim, 60
-        cfg.dtype = {"f32": _lib.F32, "bf16": _lib.BF16}[dtype]
-        cfg.max_batch, cfg.max_label_len, cfg.attn_impl = max_batch, 64, 1
         self._cfg = cfg
-        self.dim, self.num_layers, self.num_heads, self.T, self.max_batch = dim, num_layers, num_heads, seq_len, max_batch
-        self._map = _LayoutMap(dim, num_heads)
+        self.T, self.F_in, self.max_batch = seq_len, in_features, max_batch
+        self._map = layout_map
         self._h = C.c_void_p()
         _lib.check(self._lib.ishara_create(C.byref(cfg), C.byref(self._h)), "ishara_create")
         self.n_total = int(self._lib.ishara_param_total(self._h))
@@ -126,6 +116,7 @@ class ConformerEncoder:
             _lib.check(self._lib.ishara_param_info(self._h, i, C.byref(name), C.byref(nd), C.byref(sh), C.byref(off), C.byref(tr)))
             shape = (int(sh[0]),) if nd.value == 1 else (int(sh[0]), int(sh[1]))
             self.entries.append((name.value.decode(), shape, int(off.value), bool(tr.value)))
+        self.T_out = int(self._lib.ishara_encoder_output_frames(self._h))
         self.training = True
         self.device = None
         self._seed, self._steps = seed * 7919 + 17, 0
@@ -150,7 +141,7 @@ class ConformerEncoder:
                                          _lib.ptr(self.opt_slow), C.c_void_p(ws_ptr), wsb), "ishara_bind")
         # the flat trainable vector as a leaf torch optimisers can step; it aliases the library's parameter buffer
         self.flat = torch.nn.Parameter(self.params[:self.n_train], requires_grad=True)
-        self.load_state_dict(default_state_dict(self.torch_shapes(), seed))
+        self.load_state_dict(self._default_state(seed))
 
     def __del__(self):
         try:
@@ -218,13 +209,13 @@ class ConformerEncoder:
     def _forward(self, x: torch.Tensor, training: bool, seed: Optional[int] = None) -> torch.Tensor:
         if x.dim() == 2:
             x = x[None]
-        if x.shape[1:] != (self.T, self.dim):
-            raise ValueError(f"expected input [B,{self.T},{self.dim}], got {tuple(x.shape)}")
+        if x.shape[1:] != (self.T, self.F_in):
+            raise ValueError(f"expected input [B,{self.T},{self.F_in}], got {tuple(x.shape)}")
         x = x.detach().to(self.device, torch.float32).contiguous()
         B = x.shape[0]
         if B > self.max_batch:
             raise ValueError(f"batch {B} > max_batch {self.max_batch}")
-        y = torch.empty_like(x)
+        y = torch.empty((B, self.T_out, self.dim), dtype=torch.float32, device=self.device)
         if seed is None:
             seed = (self._seed + 0x9E3779B1 * self._steps) & 0xFFFFFFFF
             self._steps += 1
@@ -235,18 +226,43 @@ class ConformerEncoder:
 
     def _backward(self, dy: torch.Tensor) -> torch.Tensor:
         dy = dy.detach().to(self.device, torch.float32).contiguous()
-        dx = torch.empty_like(dy)
+        dx = torch.empty((dy.shape[0], self.T, self.F_in), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.ishara_encoder_backward(self._h, _lib.ptr(dy), dy.shape[0], _lib.ptr(dx), _stream()), "ishara_encoder_backward")
         return dx
+
+    def _default_state(self, seed):
+        return default_state_dict(self.torch_shapes(), seed)
+
+    def _apply(self, x):
+        x = torch.as_tensor(x)
+        if torch.is_grad_enabled() and self.training:
+            return _EncoderFn.apply(x.to(self.device), self.flat, self)
+        return self._forward(x, training=self.training)
+
+
+class ConformerEncoder(_TorchFamilyEncoder):
+    """conformer/conformer.py:76-87 on MI355X.  Extra keyword arguments size the device buffers: `seq_len` (frames per clip,
+    a multiple of 8, <= 512), `max_batch`, `dtype` ("bf16" storage + bf16 MFMA with fp32 accumulation, or "f32")."""
+
+    def __init__(self, dim, num_layers=7, num_heads=8, expansion_factor=4, kernel_size=31, dropout=0.1, *,
+                 seq_len=384, max_batch=64, dtype="bf16", device: Optional[str] = "cuda:0", seed=0):
+        if kernel_size % 2 == 0:
+            raise ValueError("kernel_size must be odd (padding=kernel_size//2 keeps the sequence length only then)")
+        cfg = _lib.Config()
+        cfg.family = _lib.FAMILY_TORCH_CONFORMER
+        cfg.dim, cfg.num_conv_conform_blocks, cfg.num_heads = dim, num_layers, num_heads
+        cfg.expansion_factor, cfg.transformer_kernel_size, cfg.dropout_rate = expansion_factor, kernel_size, dropout
+        cfg.frames, cfg.features, cfg.num_classes = seq_len, dim, 60
+        cfg.dtype = {"f32": _lib.F32, "bf16": _lib.BF16}[dtype]
+        cfg.max_batch, cfg.max_label_len, cfg.attn_impl = max_batch, 64, 1
+        self.dim, self.num_layers, self.num_heads = dim, num_layers, num_heads
+        self._create(cfg, _LayoutMap(dim, num_heads), dim, seq_len, max_batch, device, seed)
 
     def __call__(self, x, attn_mask=None):
         """ConformerEncoder.forward(x, attn_mask=None) — conformer.py:84-87.  `attn_mask` must be None (the reference's callers
         never pass one)."""
         if attn_mask is not None:
             raise NotImplementedError("attn_mask is not supported")
-        x = torch.as_tensor(x)
-        if torch.is_grad_enabled() and self.training:
-            return _EncoderFn.apply(x.to(self.device), self.flat, self)
-        return self._forward(x, training=self.training)
+        return self._apply(x)
 
     forward = __call__

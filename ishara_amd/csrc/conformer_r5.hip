@@ -29,12 +29,12 @@ __global__ void r5_to_f32_kernel(const T* __restrict__ x, float* __restrict__ y,
     }
 }
 static int grid_for(size_t n8) { const size_t g = (n8 + 255) / 256; return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g)); }
-static int r5_from_f32(int dt, const float* x, void* y, size_t n, hipStream_t s) {
+int r5_from_f32(int dt, const float* x, void* y, size_t n, hipStream_t s) {
     if (dt == DT_BF16) hipLaunchKernelGGL(r5_from_f32_kernel<bf16>, dim3(grid_for(n / 8)), dim3(256), 0, s, x, (bf16*)y, n / 8);
     else hipLaunchKernelGGL(r5_from_f32_kernel<float>, dim3(grid_for(n / 8)), dim3(256), 0, s, x, (float*)y, n / 8);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
-static int r5_to_f32(int dt, const void* x, float* y, size_t n, hipStream_t s) {
+int r5_to_f32(int dt, const void* x, float* y, size_t n, hipStream_t s) {
     if (dt == DT_BF16) hipLaunchKernelGGL(r5_to_f32_kernel<bf16>, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16*)x, y, n / 8);
     else hipLaunchKernelGGL(r5_to_f32_kernel<float>, dim3(grid_for(n / 8)), dim3(256), 0, s, (const float*)x, y, n / 8);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -147,16 +147,17 @@ void r5_plan_workspace(ishara_model* m) {
 }
 
 // ------------------------------------------------------------------ forward
-static int r5_ln_fwd(ishara_model* m, const Run& r, const void* x, const Norm& n, void* y, Buf mean, Buf rstd) {
+int r5_ln_fwd(ishara_model* m, const Run& r, const void* x, const Norm& n, void* y, Buf mean, Buf rstd) {
     CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(m->dt, x, m->P(n.gamma), m->P(n.beta), R5_EPS, y, m->Wf(mean), m->Wf(rstd), r.M, m->d, m->s));
     return 0;
 }
-static int r5_ffn_fwd(ishara_model* m, R5FFN& f, const Run& r, const void* x) {
+int r5_ffn_fwd(ishara_model* m, R5FFN& f, const Run& r, const void* x) {
     const int dt = m->dt;
     OpArgs no;
     EpiArgs ea; ea.pre_out = m->W(f.za); ea.act = ACT_SWISH; ea.drop = dspec(r, f.site_in, m->cfg.dropout_rate);
     CK(gemm_fwd(m, f.W1, x, dt, m->W(f.u), dt, r.M, OP_NONE, no, ea));
     EpiArgs eb; eb.resid = x; eb.drop = dspec(r, f.site_out, m->cfg.dropout_rate);
+    if (f.factor != 1.f) { eb.rowscale = m->Wf(m->fac); eb.T = m->T; }        // r = x + factor * drop(linear2(...)): fac[b] = factor for every sample
     CK(gemm_fwd(m, f.W2, m->W(f.u), dt, m->W(f.r), dt, r.M, OP_NONE, no, eb));
     return r5_ln_fwd(m, r, m->W(f.r), f.ln, m->W(f.out), f.mean, f.rstd);
 }
@@ -176,8 +177,9 @@ static int r5_mhsa_fwd(ishara_model* m, R5MHSA& a, const Run& r, const void* x) 
 
 extern "C" int ishara_encoder_forward(ishara_model* m, const float* x, int32_t B, float* y, int32_t training, uint32_t seed, ishara_stream st) {
     if (!m->ws) { ishara_set_error("ishara_encoder_forward: model is not bound"); return -1; }
-    if (m->family != ISHARA_FAMILY_TORCH_CONFORMER) { ishara_set_error("ishara_encoder_forward: handle is not an ISHARA_FAMILY_TORCH_CONFORMER model"); return -1; }
     if (B <= 0 || B > m->Bmax) { ishara_set_error("ishara_encoder_forward: batch %d outside 1..%d", B, m->Bmax); return -1; }
+    if (m->family == ISHARA_FAMILY_TORCH_SQUEEZEFORMER) return r4_forward(m, x, B, y, training, seed, (hipStream_t)st);
+    if (m->family != ISHARA_FAMILY_TORCH_CONFORMER) { ishara_set_error("ishara_encoder_forward: handle is not an encoder-only family"); return -1; }
     m->s = (hipStream_t)st;
     Run r{B, B * m->T, training, seed};
     const void* h = x;
@@ -197,12 +199,12 @@ extern "C" int ishara_encoder_forward(ishara_model* m, const float* x, int32_t B
 
 // ------------------------------------------------------------------ backward
 // each *_bwd consumes g (gradient of the module output) and writes gn (gradient of its input x)
-static int r5_ln_bwd(ishara_model* m, const Run& r, const void* g, const void* x, const Norm& n, Buf mean, Buf rstd, void* dx) {
+int r5_ln_bwd(ishara_model* m, const Run& r, const void* g, const void* x, const Norm& n, Buf mean, Buf rstd, void* dx) {
     CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0,
         launch_layernorm_bwd(m->dt, g, x, m->Wf(mean), m->Wf(rstd), m->P(n.gamma), nullptr, dx, m->G(n.gamma), m->G(n.beta), m->Wf(m->slab), r.M, m->d, m->s));
     return 0;
 }
-static int r5_ffn_bwd(ishara_model* m, R5FFN& f, const Run& r, const void* x, const void* g, void* gn) {
+int r5_ffn_bwd(ishara_model* m, R5FFN& f, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt;
     OpArgs no;
     void* dr = m->W(m->t4);                                         // gradient of r = x + drop(linear2(...)): also the residual branch
@@ -211,6 +213,10 @@ static int r5_ffn_bwd(ishara_model* m, R5FFN& f, const Run& r, const void* x, co
     const DropSpec od = dspec(r, f.site_out, m->cfg.dropout_rate);
     if (od.thr) {
         CKP(m, "map_rows", 2.0 * r.M * m->d * (double)dt_size(dt), 0, launch_map_rows(dt, MAP_DROPMASK, dr, m->W(m->t3), nullptr, od, r.M, m->T, m->d, m->s));
+        gs = m->W(m->t3);
+    }
+    if (f.factor != 1.f) {                                        // gradient of the branch = factor * dr
+        CKP(m, "map_rows", 2.0 * r.M * m->d * (double)dt_size(dt), 0, launch_map_rows(dt, MAP_ROWSCALE, gs, m->W(m->t3), m->Wf(m->fac), DropSpec{0, 0, 1.f}, r.M, m->T, m->d, m->s));
         gs = m->W(m->t3);
     }
     EpiArgs e1; e1.drop = dspec(r, f.site_in, m->cfg.dropout_rate); e1.dact = DACT_SWISH; e1.aux = m->W(f.za);
@@ -240,8 +246,9 @@ static int r5_mhsa_bwd(ishara_model* m, R5MHSA& a, const Run& r, const void* x, 
 
 extern "C" int ishara_encoder_backward(ishara_model* m, const float* dy, int32_t B, float* dx, ishara_stream st) {
     if (!m->ws || !m->grads) { ishara_set_error("ishara_encoder_backward: model is not bound (grads required)"); return -1; }
-    if (m->family != ISHARA_FAMILY_TORCH_CONFORMER) { ishara_set_error("ishara_encoder_backward: handle is not an ISHARA_FAMILY_TORCH_CONFORMER model"); return -1; }
     if (B != m->lastB || !m->last_training) { ishara_set_error("ishara_encoder_backward: call ishara_encoder_forward(training=1) with the same batch first"); return -1; }
+    if (m->family == ISHARA_FAMILY_TORCH_SQUEEZEFORMER) return r4_backward(m, dy, B, dx, (hipStream_t)st);
+    if (m->family != ISHARA_FAMILY_TORCH_CONFORMER) { ishara_set_error("ishara_encoder_backward: handle is not an encoder-only family"); return -1; }
     m->s = (hipStream_t)st;
     Run r{B, B * m->T, 1, m->last_seed};
     CK(launch_fill_u32(m->grads, (size_t)m->n_train, 0u, m->s));
@@ -267,4 +274,11 @@ extern "C" int ishara_encoder_backward(ishara_model* m, const float* dy, int32_t
     if (dx) CKP(m, "cast", 6.0 * r.M * m->d, 0, r5_to_f32(m->dt, g, dx, (size_t)r.M * m->d, m->s));
     if (!m->bucket_ev.empty()) HIP_CHECK_RET(hipEventRecord(m->bucket_ev.back(), m->s));
     return 0;
+}
+
+// frames per clip of the encoder output ([B, frames, dim]): T for the ConformerEncoder, the subsampled / reduced / recovered length
+// (convolution.py:68-69, :266-267, encoder.py:162) for the SqueezeformerEncoder
+extern "C" int32_t ishara_encoder_output_frames(const ishara_model* m) {
+    if (m->family == ISHARA_FAMILY_TORCH_SQUEEZEFORMER) return r4_output_frames(m);
+    return m->T;
 }

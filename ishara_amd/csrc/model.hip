@@ -295,7 +295,22 @@ static void plan_workspace(ishara_model* m) {
 extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
     if (!cfg || !out) { ishara_set_error("ishara_create: null argument"); return -1; }
     ishara_config c = *cfg;
-    if (c.family != ISHARA_FAMILY_KERAS_HYBRID && c.family != ISHARA_FAMILY_TORCH_CONFORMER) { ishara_set_error("family=%d unknown", c.family); return -1; }
+    if (c.family != ISHARA_FAMILY_KERAS_HYBRID && c.family != ISHARA_FAMILY_TORCH_CONFORMER && c.family != ISHARA_FAMILY_TORCH_SQUEEZEFORMER) { ishara_set_error("family=%d unknown", c.family); return -1; }
+    if (c.family == ISHARA_FAMILY_TORCH_SQUEEZEFORMER) {    // squeezeformer/encoder.py: its own front end (conv2d subsampling), no head, no CTC; any frame count
+        CK(r4_validate(c));
+        if (c.dim <= 0 || c.dim % 8 != 0 || c.dim > 512 || c.num_heads <= 0 || c.dim % c.num_heads != 0) { ishara_set_error("encoder_dim=%d / heads=%d unsupported", c.dim, c.num_heads); return -1; }
+        if (c.transformer_kernel_size < 1 || c.transformer_kernel_size > 31 || c.transformer_kernel_size % 2 == 0) { ishara_set_error("conv_kernel_size must be odd, 1..31"); return -1; }
+        if (c.max_batch <= 0 || (c.dtype != ISHARA_F32 && c.dtype != ISHARA_BF16)) { ishara_set_error("max_batch / dtype unsupported"); return -1; }
+        ishara_model* m = new ishara_model();
+        m->cfg = c; m->dt = c.dtype == ISHARA_BF16 ? DT_BF16 : DT_F32;
+        m->d = c.dim; m->T = c.frames; m->F = c.features; m->C = 60; m->H = c.num_heads; m->dh = c.dim / c.num_heads;
+        m->dtop = 2 * c.dim; m->Bmax = c.max_batch; m->L = 64;
+        m->family = c.family;
+        { const char* gv = getenv("ISHARA_WS_GUARD"); m->guard = gv && gv[0] == '1'; }
+        r4_build_graph(m); r4_plan_workspace(m);
+        *out = m;
+        return 0;
+    }
     if (c.family == ISHARA_FAMILY_TORCH_CONFORMER) {      // conformer/conformer.py: no stem, no head, no CTC — the encoder stack only
         CK(r5_validate(c));
         c.features = c.dim; c.num_conv_per_block = 0; c.num_conv_squeeze_blocks = 0;
@@ -345,6 +360,7 @@ extern "C" int ishara_create(const ishara_config* cfg, ishara_model** out) {
 }
 extern "C" void ishara_destroy(ishara_model* m) {
     if (m) for (auto e : m->bucket_ev) (void)hipEventDestroy(e);
+    if (m && m->r4) r4_destroy(m);
     delete m;
 }
 extern "C" int64_t ishara_param_total(const ishara_model* m) { return m->n_total; }
@@ -407,6 +423,7 @@ extern "C" int ishara_bind(ishara_model* m, float* params, float* grads, float* 
         std::vector<uint32_t> pat(64, 0xA5C3A5C3u);
         for (size_t off : m->guard_offs) HIP_CHECK_RET(hipMemcpy(m->ws + off, pat.data(), 256, hipMemcpyHostToDevice));
     }
+    if (m->family == ISHARA_FAMILY_TORCH_SQUEEZEFORMER) CK(r4_bind(m));
     if (m->family == ISHARA_FAMILY_KERAS_HYBRID) HIP_CHECK_RET(hipMemcpy(m->ws + m->pe.off, m->pe_host.data(), m->pe_host.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
@@ -531,13 +548,19 @@ int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
     CK(gemm_fwd(m, c.Wp1, x, dt, m->W(c.g), dt, r.M, OP_NONE, no, e0));
-    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), m->P(c.dwb), m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), c.dwb >= 0 ? m->P(c.dwb) : nullptr, m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));
     const float var_corr = c.bn_unbiased && B * T > 1 ? (float)((double)B * T / ((double)B * T - 1.0)) : 1.f;
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), c.bn_eps, c.bn_keep,
                           m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s, var_corr));
     CKP(m, "col_affine", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_col_affine(dt, m->W(c.v), m->Wf(c.a), m->Wf(c.bsh), m->W(c.bnv), r.M, d, m->s));
+    const void* pin = m->W(c.bnv);
+    if (c.swish_after_bn) {
+        CKP(m, "map_rows", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_SWISH, m->W(c.bnv), m->W(c.sw), nullptr, DropSpec{0, 0, 1.f}, r.M, T, d, m->s));
+        pin = m->W(c.sw);
+    }
     EpiArgs e2; e2.resid = x;
-    CK(gemm_fwd(m, c.Wp2, m->W(c.bnv), dt, m->W(c.r), dt, r.M, OP_NONE, no, e2));
+    if (c.has_out_drop) e2.drop = dspec(r, c.site_out, m->cfg.dropout_rate);
+    CK(gemm_fwd(m, c.Wp2, pin, dt, m->W(c.r), dt, r.M, OP_NONE, no, e2));
     CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, m->W(c.r), m->P(c.ln.gamma), m->P(c.ln.beta), c.ln_eps, m->W(c.out), m->Wf(c.lnmean), m->Wf(c.lnrstd), r.M, d, m->s));
     return 0;
 }
@@ -686,18 +709,27 @@ static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x,
 
 int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
-    OpArgs no; EpiArgs e0;
+    OpArgs no;
     CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), m->Wf(m->slab), r.M, d, m->s));   // dr
-    CK(gemm_dgrad(m, c.Wp2, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // d bn(v)
-    CK(gemm_wgrad(m, c.Wp2, m->W(c.bnv), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    const void* gs = m->W(m->t1);                          // gradient through the module's output dropout
+    if (c.has_out_drop) {
+        const DropSpec od = dspec(r, c.site_out, m->cfg.dropout_rate);
+        if (od.thr) {
+            CKP(m, "map_rows", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_DROPMASK, m->W(m->t1), m->W(m->t3), nullptr, od, r.M, T, d, m->s));
+            gs = m->W(m->t3);
+        }
+    }
+    EpiArgs es; if (c.swish_after_bn) { es.dact = DACT_SWISH; es.aux = m->W(c.bnv); }
+    CK(gemm_dgrad(m, c.Wp2, gs, dt, m->W(m->t2), r.M, OP_NONE, no, es));                                          // d bn(v)
+    CK(gemm_wgrad(m, c.Wp2, c.swish_after_bn ? m->W(c.sw) : m->W(c.bnv), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
     CKP(m, "bn_bwd_finalize", 0, 0, launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(c.bn.gamma), m->G(c.bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
     DwBnArgs bn; bn.h = m->W(c.v); bn.mean = m->Wf(c.mean); bn.rstd = m->Wf(c.rstd); bn.a = m->Wf(c.a); bn.E = m->Wf(m->Ecol); bn.Fc = m->Wf(m->Fc);
     int fused = 0;
-    CKP(m, "dwconv_bwd", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, (fused = launch_dwconv_bwd_bn(dt, DWIN_GLU, m->W(m->t2), bn, m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s)) < 0 ? fused : 0);   // dg [M,2d]
+    CKP(m, "dwconv_bwd", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, (fused = launch_dwconv_bwd_bn(dt, DWIN_GLU, m->W(m->t2), bn, m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), c.dwb >= 0 ? m->G(c.dwb) : nullptr, m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s)) < 0 ? fused : 0);   // dg [M,2d]
     if (!fused) {
         CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv
-        CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), m->G(c.dwb), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
+        CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), c.dwb >= 0 ? m->G(c.dwb) : nullptr, m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
     }
     EpiArgs e2; e2.resid = m->W(m->t1);
     CK(gemm_dgrad(m, c.Wp1, m->W(m->t3), dt, gn, r.M, OP_NONE, no, e2));

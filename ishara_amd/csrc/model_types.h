@@ -63,10 +63,13 @@ struct ConfConv {
     // Keras defaults (c5:249-309); the torch family overrides them (nn.BatchNorm1d: eps 1e-5, momentum 0.1 on the NEW value, unbiased
     // running variance; nn.LayerNorm eps 1e-5)
     float bn_eps = 1e-3f, bn_keep = 0.99f, ln_eps = 1e-3f; int bn_unbiased = 0;
+    // squeezeformer/convolution.py:226-238: Swish between the BatchNorm and the second pointwise conv (sw = swish(bnv)), Dropout on its output
+    int swish_after_bn = 0; uint32_t site_out = 0; int has_out_drop = 0; Buf sw;
     Buf g, v, bnv, ssum, ssq, mean, rstd, a, bsh, r, lnmean, lnrstd, out;
 };
 // ---- torch ConformerEncoder family (conformer/conformer.py:6-87): post-LN sub-modules
-struct R5FFN { DenseW W1, W2; Norm ln; uint32_t site_in = 0, site_out = 0; Buf za, u, r, mean, rstd, out; };
+struct R5FFN { DenseW W1, W2; Norm ln; uint32_t site_in = 0, site_out = 0; Buf za, u, r, mean, rstd, out;
+               float factor = 1.f; };      // r = x + factor * ffn(x)   (squeezeformer half_step_residual: 0.5)
 struct R5MHSA { DenseW Wqkv, Wp; Norm ln; uint32_t site_attn = 0; Buf q, k, vt, o, lse, maskw, r, mean, rstd, out; };
 struct R5Block { R5FFN ffn1; R5MHSA mha; ConfConv conv; R5FFN ffn2; Norm ln; Buf mean, rstd, out; };
 struct Layer {            // one entry of the sequential graph
@@ -110,7 +113,8 @@ struct ishara_model {
     std::vector<ConfBlock> conf;
     std::vector<Layer> layers;
     int family = 0;                    // 0: Keras get_model hybrid; 1: torch ConformerEncoder (conformer_r5.hip)
-    std::vector<R5Block> r5; Buf r5_x, t4;
+    std::vector<R5Block> r5; Buf r5_x, t4, fac;          // fac: [Bmax] floats, all = the FFN residual factor (epilogue row scale)
+    struct R4State* r4 = nullptr;                          // torch Squeezeformer family (squeezeformer_r4.hip)
     DenseW topW, clsW; uint32_t head_site = 0; Buf head_hh;
     uint32_t nsites = 0;
     std::vector<DenseW*> denses;
@@ -181,7 +185,22 @@ int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* 
 int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0, int nb_valid = 0);
 int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x);
 int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn);
+int r5_ffn_fwd(ishara_model* m, R5FFN& f, const Run& r, const void* x);
+int r5_ffn_bwd(ishara_model* m, R5FFN& f, const Run& r, const void* x, const void* g, void* gn);
+int r5_ln_fwd(ishara_model* m, const Run& r, const void* x, const Norm& n, void* y, Buf mean, Buf rstd);
+int r5_ln_bwd(ishara_model* m, const Run& r, const void* g, const void* x, const Norm& n, Buf mean, Buf rstd, void* dx);
+int r5_from_f32(int dt, const float* x, void* y, size_t n, hipStream_t s);
+int r5_to_f32(int dt, const void* x, float* y, size_t n, hipStream_t s);
 // torch ConformerEncoder family (conformer_r5.hip)
 int r5_validate(const ishara_config& c);
 void r5_build_graph(ishara_model* m);
 void r5_plan_workspace(ishara_model* m);
+// torch Squeezeformer family (squeezeformer_r4.hip)
+int r4_validate(const ishara_config& c);
+void r4_build_graph(ishara_model* m);
+void r4_plan_workspace(ishara_model* m);
+int r4_bind(ishara_model* m);
+void r4_destroy(ishara_model* m);
+int r4_output_frames(const ishara_model* m);
+int r4_forward(ishara_model* m, const float* x, int32_t B, float* y, int32_t training, uint32_t seed, hipStream_t st);
+int r4_backward(ishara_model* m, const float* dy, int32_t B, float* dx, hipStream_t st);

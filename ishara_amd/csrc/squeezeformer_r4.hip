@@ -1,0 +1,899 @@
+// The torch Squeezeformer family of the reference (squeezeformer/{attention,modules,convolution,encoder}.py):
+//   R1  RelativeMultiHeadAttention (attention.py:25-110): Transformer-XL attention — content score (q + u_bias) . k plus positional score
+//       (q + v_bias) . p with p = pos_proj(RelPositionalEncoding); `_relative_shift` (:102-110) in closed form: the key j of query i
+//       reads row T-1-i+j of the [2T-1, d] table.  Flash-style kernels below (no [T, T] matrix in memory), forward and three backward
+//       passes (dq + du/dv, dk/dv, dpos) that recompute the probabilities from the saved log-sum-exp.
+//   R2  RelPositionalEncoding (modules.py:59-108): table built on the host at create time (fp32 sin / cos, positions T-1 .. -(T-1)).
+//   R3  ConvModule (convolution.py:199-238): the ConfConv composition of model.hip with Swish after the BatchNorm, no depthwise bias.
+//   R4  post-LN SqueezeformerBlock (encoder.py:208-247) with the half-step FFN residual, DepthwiseConv2dSubsampling
+//       (convolution.py:39-73), TimeReductionLayer (:241-269), recover_resolution (modules.py:137-142) and the encoder loop
+//       (encoder.py:135-166) with its ResidualConnectionModule around the reduced-rate blocks (:88-103).
+// Parameter entries carry the reference's state_dict keys, in state_dict order, arrays in the kernels' layout (Linear / pointwise
+// weights [in,out], 3x3 kernels [C,9], depthwise [k,d], u/v bias [d]); ishara_amd/squeezeformer.py converts to and from torch's.
+#include "model_types.h"
+
+static const float R4_EPS = 1e-5f;
+
+// ------------------------------------------------------------------ state
+struct RelMHSA {
+    DenseW Wq, Wk, Wv, Wpos, Wo; int u = -1, v = -1; Norm ln; uint32_t site_attn = 0, site_out = 0;
+    Buf q, k, vv, o, lse, posp, r, mean, rstd, out;
+};
+struct R4Layer { RelMHSA mha; R5FFN ffn1; ConfConv conv; R5FFN ffn2; int T = 0; bool wrapped = false; Buf wrap_out; int pe = 0; };
+struct R4State {
+    int w1 = -1, b1 = -1, w2 = -1, b2 = -1, trw = -1, trb = -1;
+    DenseW Win, Wred, Wrec;
+    int T0 = 0, F = 0, T1 = 0, F1 = 0, T2 = 0, F2 = 0, T3 = 0, Fr = 0, Kp = 0, Trec = 0, Tout = 0;
+    int reduce = 0, recover = 0; uint32_t site_in = 0;
+    Buf y1, dz1, dwred, sub, h0, trpre, trout, red, rep, crop, rec, gskip, gwrap, dsub, dqb, dkb, dvb, dposp;
+    std::vector<R4Layer> layers;
+    std::vector<int> pe_T; std::vector<Buf> pe32, pedt; std::vector<std::vector<float>> pe_host;
+};
+
+// ------------------------------------------------------------------ small kernels
+template <typename T> DEVI float ldf(const T* p) { return to_f(*p); }
+
+// x [B,T0,F] f32 -> y1 [B,d,T1,F1] f32 = relu(conv3x3 s2)        (convolution.py:56)
+__global__ void r4_sub1_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y1,
+                            int B, int T0, int F, int d, int T1, int F1) {
+    const size_t n = (size_t)B * d * T1 * F1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int f1 = (int)(i % F1), t1 = (int)((i / F1) % T1), c = (int)((i / ((size_t)F1 * T1)) % d), bb = (int)(i / ((size_t)F1 * T1 * d));
+        float acc = b[c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc += w[c * 9 + a * 3 + e] * x[((size_t)bb * T0 + 2 * t1 + a) * F + 2 * f1 + e];
+        y1[i] = fmaxf(acc, 0.f);
+    }
+}
+// y1 -> sub [B*T2, d*F2] (storage type) = relu(depthwise conv3x3 s2), channel-major features   (:58-66)
+template <typename T>
+__global__ void r4_sub2_fwd(const float* __restrict__ y1, const float* __restrict__ w, const float* __restrict__ b, T* __restrict__ sub,
+                            int B, int d, int T1, int F1, int T2, int F2) {
+    const size_t n = (size_t)B * T2 * d * F2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int f2 = (int)(i % F2), c = (int)((i / F2) % d), t2 = (int)((i / ((size_t)F2 * d)) % T2), bb = (int)(i / ((size_t)F2 * d * T2));
+        float acc = b[c];
+        const float* src = y1 + (((size_t)bb * d + c) * T1) * F1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc += w[c * 9 + a * 3 + e] * src[(size_t)(2 * t2 + a) * F1 + 2 * f2 + e];
+        sub[i] = from_f<T>(fmaxf(acc, 0.f));
+    }
+}
+// backward of the depthwise conv: dz2 = dsub * (sub > 0); dw2, db2 (atomics) and dy1 (scatter-free gather form)
+template <typename T>
+__global__ void r4_sub2_bwd_w(const T* __restrict__ dsub, const T* __restrict__ sub, const float* __restrict__ y1, float* __restrict__ dw, float* __restrict__ db,
+                              int B, int d, int T1, int F1, int T2, int F2) {
+    // one workgroup per channel: 10 sums over (b, t2, f2)
+    const int c = blockIdx.x;
+    float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n = B * T2 * F2;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int f2 = i % F2, t2 = (i / F2) % T2, bb = i / (F2 * T2);
+        const size_t o = (((size_t)bb * T2 + t2) * d + c) * F2 + f2;
+        const float g = ldf(sub + o) > 0.f ? ldf(dsub + o) : 0.f;
+        const float* src = y1 + (((size_t)bb * d + c) * T1) * F1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc[a * 3 + e] += g * src[(size_t)(2 * t2 + a) * F1 + 2 * f2 + e];
+        acc[9] += g;
+    }
+    __shared__ float red[10][256];
+    for (int q = 0; q < 10; ++q) red[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) for (int q = 0; q < 10; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) dw[c * 9 + threadIdx.x] += red[threadIdx.x][0];
+    if (threadIdx.x == 9) db[c] += red[9][0];
+}
+template <typename T>
+__global__ void r4_sub2_bwd_x(const T* __restrict__ dsub, const T* __restrict__ sub, const float* __restrict__ w, const float* __restrict__ y1, float* __restrict__ dz1,
+                              int B, int d, int T1, int F1, int T2, int F2) {
+    // dz1[b,c,t1,f1] = (y1 > 0) * sum_{a,e: (t1-a)/2, (f1-e)/2 integral and in range} w[c,a,e] * dz2[b, (t1-a)/2, c, (f1-e)/2]
+    const size_t n = (size_t)B * d * T1 * F1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int f1 = (int)(i % F1), t1 = (int)((i / F1) % T1), c = (int)((i / ((size_t)F1 * T1)) % d), bb = (int)(i / ((size_t)F1 * T1 * d));
+        float acc = 0.f;
+        if (y1[i] > 0.f) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int tt = t1 - a;
+                if (tt < 0 || (tt & 1) || (tt >> 1) >= T2) continue;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const int ff = f1 - e;
+                    if (ff < 0 || (ff & 1) || (ff >> 1) >= F2) continue;
+                    const size_t o = (((size_t)bb * T2 + (tt >> 1)) * d + c) * F2 + (ff >> 1);
+                    if (ldf(sub + o) > 0.f) acc += w[c * 9 + a * 3 + e] * ldf(dsub + o);
+                }
+            }
+        }
+        dz1[i] = acc;
+    }
+}
+// first conv backward: dw1[c,9], db1[c] from dz1 and x (one workgroup per channel); dx optional (atomic-free gather over channels is O(d): skipped unless asked)
+__global__ void r4_sub1_bwd_w(const float* __restrict__ dz1, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
+                              int B, int T0, int F, int d, int T1, int F1) {
+    const int c = blockIdx.x;
+    float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n = B * T1 * F1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int f1 = i % F1, t1 = (i / F1) % T1, bb = i / (F1 * T1);
+        const float g = dz1[(((size_t)bb * d + c) * T1 + t1) * F1 + f1];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc[a * 3 + e] += g * x[((size_t)bb * T0 + 2 * t1 + a) * F + 2 * f1 + e];
+        acc[9] += g;
+    }
+    __shared__ float red[10][256];
+    for (int q = 0; q < 10; ++q) red[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) for (int q = 0; q < 10; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) dw[c * 9 + threadIdx.x] += red[threadIdx.x][0];
+    if (threadIdx.x == 9) db[c] += red[9][0];
+}
+__global__ void r4_sub1_bwd_x(const float* __restrict__ dz1, const float* __restrict__ w, float* __restrict__ dx, int B, int T0, int F, int d, int T1, int F1) {
+    const size_t n = (size_t)B * T0 * F;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F), t = (int)((i / F) % T0), bb = (int)(i / ((size_t)F * T0));
+        float acc = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            const int tt = t - a;
+            if (tt < 0 || (tt & 1) || (tt >> 1) >= T1) continue;
+            for (int e = 0; e < 3; ++e) {
+                const int ff = f - e;
+                if (ff < 0 || (ff & 1) || (ff >> 1) >= F1) continue;
+                for (int c = 0; c < d; ++c) acc += w[c * 9 + a * 3 + e] * dz1[(((size_t)bb * d + c) * T1 + (tt >> 1)) * F1 + (ff >> 1)];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// TimeReductionLayer (convolution.py:241-269): one 3x3 stride-2 kernel over the (time, feature) plane of h [B,Tin,d], Swish;
+// out [B*Tr, Kp] (columns >= Fr are zero padding of the following Linear's K), pre [B,Tr,Fr] f32 saved for the backward pass
+template <typename T>
+__global__ void r4_tred_fwd(const T* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ pre, T* __restrict__ out,
+                            int B, int Tin, int d, int Tr, int Fr, int Kp) {
+    const size_t n = (size_t)B * Tr * Kp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i % Kp), t = (int)((i / Kp) % Tr), bb = (int)(i / ((size_t)Kp * Tr));
+        if (f >= Fr) { out[i] = from_f<T>(0.f); continue; }
+        float acc = b[0];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc += w[a * 3 + e] * ldf(h + ((size_t)bb * Tin + 2 * t + a) * d + 2 * f + e);
+        pre[((size_t)bb * Tr + t) * Fr + f] = acc;
+        out[i] = from_f<T>(swishf_(acc));
+    }
+}
+template <typename T>
+__global__ void r4_tred_bwd_w(const T* __restrict__ dout, const float* __restrict__ pre, const T* __restrict__ h, float* __restrict__ dw, float* __restrict__ db,
+                              int B, int Tin, int d, int Tr, int Fr, int Kp) {
+    float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t n = (size_t)B * Tr * Fr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i % Fr), t = (int)((i / Fr) % Tr), bb = (int)(i / ((size_t)Fr * Tr));
+        const float g = ldf(dout + ((size_t)bb * Tr + t) * Kp + f) * dswishf_(pre[i]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc[a * 3 + e] += g * ldf(h + ((size_t)bb * Tin + 2 * t + a) * d + 2 * f + e);
+        acc[9] += g;
+    }
+    __shared__ float red[10][256];
+    for (int q = 0; q < 10; ++q) red[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) for (int q = 0; q < 10; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) atomicAdd(&dw[threadIdx.x], red[threadIdx.x][0]);
+    if (threadIdx.x == 9) atomicAdd(&db[0], red[9][0]);
+}
+// dh[b,t,f] = extra[b,t,f] (gradient arriving through the recover skip, or 0) + sum_{a,e} w[a,e] * dz[b, (t-a)/2, (f-e)/2]
+template <typename T>
+__global__ void r4_tred_bwd_x(const T* __restrict__ dout, const float* __restrict__ pre, const float* __restrict__ w, const T* __restrict__ extra, T* __restrict__ dh,
+                              int B, int Tin, int d, int Tr, int Fr, int Kp) {
+    const size_t n = (size_t)B * Tin * d;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i % d), t = (int)((i / d) % Tin), bb = (int)(i / ((size_t)d * Tin));
+        float acc = extra ? ldf(extra + i) : 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int tt = t - a;
+            if (tt < 0 || (tt & 1) || (tt >> 1) >= Tr) continue;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int ff = f - e;
+                if (ff < 0 || (ff & 1) || (ff >> 1) >= Fr) continue;
+                const size_t o = ((size_t)bb * Tr + (tt >> 1));
+                acc += w[a * 3 + e] * ldf(dout + o * Kp + (ff >> 1)) * dswishf_(pre[o * Fr + (ff >> 1)]);
+            }
+        }
+        dh[i] = from_f<T>(acc);
+    }
+}
+// generic row maps over [B, Tdst, d]: MODE 0 dst[b,t] = src[b, t/2] (recover_resolution, src has Tsrc rows per sample);
+// MODE 1 dst[b,t] = src[b,t] for t < Tdst (crop of a longer sequence); MODE 2 dst[b,t] = src[b,2t] + src[b,2t+1] (backward of MODE 0);
+// MODE 3 dst[b,t] = t < Tsrc ? src[b,t] : 0 (backward of the crop into the longer sequence); MODE 4 dst = a + src (same shape)
+template <typename T, int MODE>
+__global__ void r4_rows(const T* __restrict__ src, const T* __restrict__ a, T* __restrict__ dst, int B, int Tdst, int Tsrc, int d) {
+    const size_t n = (size_t)B * Tdst * d;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % d), t = (int)((i / d) % Tdst), bb = (int)(i / ((size_t)d * Tdst));
+        float v;
+        if (MODE == 0) v = ldf(src + ((size_t)bb * Tsrc + (t >> 1)) * d + e);
+        else if (MODE == 1) v = ldf(src + ((size_t)bb * Tsrc + t) * d + e);
+        else if (MODE == 2) v = ldf(src + ((size_t)bb * Tsrc + 2 * t) * d + e) + ldf(src + ((size_t)bb * Tsrc + 2 * t + 1) * d + e);
+        else if (MODE == 3) v = t < Tsrc ? ldf(src + ((size_t)bb * Tsrc + t) * d + e) : 0.f;
+        else v = ldf(a + i) + ldf(src + i);
+        dst[i] = from_f<T>(v);
+    }
+}
+__global__ void r4_axpy_f32(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += x[i];
+}
+__global__ void r4_fill_f32(float* p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+static int g1d(size_t n) { const size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+#define R4_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
+template <int MODE>
+static int r4_rows_launch(int dt, const void* src, const void* a, void* dst, int B, int Tdst, int Tsrc, int d, hipStream_t s) {
+    const int grid = g1d((size_t)B * Tdst * d);
+    if (dt == DT_BF16) hipLaunchKernelGGL((r4_rows<bf16, MODE>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (const bf16*)a, (bf16*)dst, B, Tdst, Tsrc, d);
+    else hipLaunchKernelGGL((r4_rows<float, MODE>), dim3(grid), dim3(256), 0, s, (const float*)src, (const float*)a, (float*)dst, B, Tdst, Tsrc, d);
+    return R4_OK();
+}
+
+// ------------------------------------------------------------------ R1: relative-position attention
+// q, k, v [B*T, d] (head h in columns h*DH ..), posp [2T-1, d] f32 (pos_proj of the table), u, vb [d] f32.  One thread per query
+// (forward, dq) / key (dk, dv) / table row (dpos); the other side streams through LDS in chunks.  score(i,j) = scale * ((q_i+u).k_j +
+// (q_i+vb).posp[T-1-i+j]); softmax over j; inverted dropout on the probabilities (keyed by (b*H+h)*T+i, j).
+#define RA_QB 64      // threads per workgroup = queries / keys / table rows per workgroup
+#define RA_KT 32      // rows of the streamed side per chunk
+
+template <typename T, int DH>
+__global__ __launch_bounds__(RA_QB) void relattn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ posp,
+                                                            const float* __restrict__ u, const float* __restrict__ vb, T* __restrict__ o, float* __restrict__ lse,
+                                                            int H, int Tn, float scale, DropSpec drop) {
+    __shared__ float Ks[RA_KT][DH + 1], Vs[RA_KT][DH + 1], Ps[RA_KT + RA_QB - 1][DH + 1];
+    const int d = H * DH, bh = blockIdx.y, b = bh / H, h = bh % H, i0 = blockIdx.x * RA_QB, i = i0 + threadIdx.x;
+    const bool act = i < Tn;
+    float qu[DH], qv[DH], acc[DH];
+    {
+        const T* qp = q + ((size_t)b * Tn + (act ? i : 0)) * d + h * DH;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) { const float x = ldf(qp + e); qu[e] = x + u[h * DH + e]; qv[e] = x + vb[h * DH + e]; acc[e] = 0.f; }
+    }
+    float mx = -3.0e38f, l = 0.f;
+    const uint32_t rk = rng_row_key(drop.key, (uint32_t)(bh * Tn + i));
+    for (int j0 = 0; j0 < Tn; j0 += RA_KT) {
+        const int rbase = Tn - 1 - (i0 + RA_QB - 1) + j0;
+        __syncthreads();
+        for (int x = threadIdx.x; x < RA_KT * DH; x += RA_QB) {
+            const int jj = x / DH, e = x % DH, j = j0 + jj;
+            Ks[jj][e] = j < Tn ? ldf(k + ((size_t)b * Tn + j) * d + h * DH + e) : 0.f;
+            Vs[jj][e] = j < Tn ? ldf(v + ((size_t)b * Tn + j) * d + h * DH + e) : 0.f;
+        }
+        for (int x = threadIdx.x; x < (RA_KT + RA_QB - 1) * DH; x += RA_QB) {
+            const int rr = x / DH, e = x % DH, r = rbase + rr;
+            Ps[rr][e] = (r >= 0 && r < 2 * Tn - 1) ? posp[(size_t)r * d + h * DH + e] : 0.f;
+        }
+        __syncthreads();
+        if (!act) continue;
+        const int pr0 = i0 + RA_QB - 1 - i;
+        for (int jj = 0; jj < RA_KT && j0 + jj < Tn; ++jj) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) s += qu[e] * Ks[jj][e] + qv[e] * Ps[pr0 + jj][e];
+            s *= scale;
+            const float mn = fmaxf(mx, s), corr = __expf(mx - mn), p = __expf(s - mn);
+            l = l * corr + p;
+            const float pd = (drop.thr == 0u || rng_keep(rk, (uint32_t)(j0 + jj), drop.thr)) ? p * drop.scale : 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) acc[e] = acc[e] * corr + pd * Vs[jj][e];
+            mx = mn;
+        }
+    }
+    if (act) {
+        const float inv = 1.f / l;
+        T* op = o + ((size_t)b * Tn + i) * d + h * DH;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) op[e] = from_f<T>(acc[e] * inv);
+        lse[(size_t)bh * Tn + i] = mx + __logf(l);
+    }
+}
+
+// dq (content + positional parts), delta_i = rowsum(dO . O), and the u_bias / v_bias gradients (workgroup sums, then one atomic each)
+template <typename T, int DH>
+__global__ __launch_bounds__(RA_QB) void relattn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ posp,
+                                                               const float* __restrict__ u, const float* __restrict__ vb, const T* __restrict__ o, const T* __restrict__ dO,
+                                                               const float* __restrict__ lse, float* __restrict__ delta, T* __restrict__ dq,
+                                                               float* __restrict__ du, float* __restrict__ dvb, int H, int Tn, float scale, DropSpec drop) {
+    __shared__ float Ks[RA_KT][DH + 1], Vs[RA_KT][DH + 1], Ps[RA_KT + RA_QB - 1][DH + 1];
+    const int d = H * DH, bh = blockIdx.y, b = bh / H, h = bh % H, i0 = blockIdx.x * RA_QB, i = i0 + threadIdx.x;
+    const bool act = i < Tn;
+    float qu[DH], qv[DH], go[DH], dqc[DH], dqp[DH];
+    float D = 0.f, L = 0.f;
+    {
+        const size_t row = ((size_t)b * Tn + (act ? i : 0)) * d + h * DH;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            const float x = ldf(q + row + e);
+            qu[e] = x + u[h * DH + e]; qv[e] = x + vb[h * DH + e];
+            go[e] = act ? ldf(dO + row + e) : 0.f;
+            D += go[e] * ldf(o + row + e);
+            dqc[e] = 0.f; dqp[e] = 0.f;
+        }
+        if (act) { L = lse[(size_t)bh * Tn + i]; delta[(size_t)bh * Tn + i] = D; }
+    }
+    const uint32_t rk = rng_row_key(drop.key, (uint32_t)(bh * Tn + i));
+    for (int j0 = 0; j0 < Tn; j0 += RA_KT) {
+        const int rbase = Tn - 1 - (i0 + RA_QB - 1) + j0;
+        __syncthreads();
+        for (int x = threadIdx.x; x < RA_KT * DH; x += RA_QB) {
+            const int jj = x / DH, e = x % DH, j = j0 + jj;
+            Ks[jj][e] = j < Tn ? ldf(k + ((size_t)b * Tn + j) * d + h * DH + e) : 0.f;
+            Vs[jj][e] = j < Tn ? ldf(v + ((size_t)b * Tn + j) * d + h * DH + e) : 0.f;
+        }
+        for (int x = threadIdx.x; x < (RA_KT + RA_QB - 1) * DH; x += RA_QB) {
+            const int rr = x / DH, e = x % DH, r = rbase + rr;
+            Ps[rr][e] = (r >= 0 && r < 2 * Tn - 1) ? posp[(size_t)r * d + h * DH + e] : 0.f;
+        }
+        __syncthreads();
+        if (!act) continue;
+        const int pr0 = i0 + RA_QB - 1 - i;
+        for (int jj = 0; jj < RA_KT && j0 + jj < Tn; ++jj) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { s += qu[e] * Ks[jj][e] + qv[e] * Ps[pr0 + jj][e]; dp += go[e] * Vs[jj][e]; }
+            const float p = __expf(s * scale - L);
+            if (!(drop.thr == 0u || rng_keep(rk, (uint32_t)(j0 + jj), drop.thr))) dp = 0.f; else dp *= drop.scale;
+            const float dS = p * (dp - D) * scale;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { dqc[e] += dS * Ks[jj][e]; dqp[e] += dS * Ps[pr0 + jj][e]; }
+        }
+    }
+    if (act) {
+        T* dp_ = dq + ((size_t)b * Tn + i) * d + h * DH;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) dp_[e] = from_f<T>(dqc[e] + dqp[e]);
+    }
+    // u_bias gradient = sum over queries of the content part, v_bias gradient = of the positional part
+    __syncthreads();
+    float (*red)[DH + 1] = Ps;       // RA_QB rows available
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int e = 0; e < DH; ++e) red[threadIdx.x][e] = act ? (pass == 0 ? dqc[e] : dqp[e]) : 0.f;
+        __syncthreads();
+        for (int e = threadIdx.x; e < DH; e += RA_QB) {
+            float s = 0.f;
+            for (int t = 0; t < RA_QB; ++t) s += red[t][e];
+            atomicAdd(&(pass == 0 ? du : dvb)[h * DH + e], s);
+        }
+        __syncthreads();
+    }
+}
+
+// dk, dv: one thread per key, queries streamed
+template <typename T, int DH>
+__global__ __launch_bounds__(RA_QB) void relattn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ posp,
+                                                                const float* __restrict__ u, const float* __restrict__ vb, const T* __restrict__ dO,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv,
+                                                                int H, int Tn, float scale, DropSpec drop) {
+    __shared__ float Qs[RA_KT][DH + 1], Gs[RA_KT][DH + 1], Ps[RA_KT + RA_QB - 1][DH + 1], Ls[RA_KT], Ds[RA_KT];
+    const int d = H * DH, bh = blockIdx.y, b = bh / H, h = bh % H, j0 = blockIdx.x * RA_QB, j = j0 + threadIdx.x;
+    const bool act = j < Tn;
+    float kk[DH], vv[DH], ak[DH], av[DH], uu[DH], vbv[DH];
+    float uk = 0.f;
+    {
+        const size_t row = ((size_t)b * Tn + (act ? j : 0)) * d + h * DH;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            kk[e] = ldf(k + row + e); vv[e] = ldf(v + row + e); ak[e] = 0.f; av[e] = 0.f;
+            uu[e] = u[h * DH + e]; vbv[e] = vb[h * DH + e];
+            uk += uu[e] * kk[e];
+        }
+    }
+    for (int i0 = 0; i0 < Tn; i0 += RA_KT) {
+        // rows of the table this chunk needs: r = T-1-i+j for i in [i0, i0+KT), j in [j0, j0+QB): from T-1-(i0+KT-1)+j0
+        const int rbase = Tn - 1 - (i0 + RA_KT - 1) + j0;
+        __syncthreads();
+        for (int x = threadIdx.x; x < RA_KT * DH; x += RA_QB) {
+            const int ii = x / DH, e = x % DH, i = i0 + ii;
+            Qs[ii][e] = i < Tn ? ldf(q + ((size_t)b * Tn + i) * d + h * DH + e) : 0.f;
+            Gs[ii][e] = i < Tn ? ldf(dO + ((size_t)b * Tn + i) * d + h * DH + e) : 0.f;
+        }
+        for (int x = threadIdx.x; x < RA_KT; x += RA_QB) { const int i = i0 + x; Ls[x] = i < Tn ? lse[(size_t)bh * Tn + i] : 0.f; Ds[x] = i < Tn ? delta[(size_t)bh * Tn + i] : 0.f; }
+        for (int x = threadIdx.x; x < (RA_KT + RA_QB - 1) * DH; x += RA_QB) {
+            const int rr = x / DH, e = x % DH, r = rbase + rr;
+            Ps[rr][e] = (r >= 0 && r < 2 * Tn - 1) ? posp[(size_t)r * d + h * DH + e] : 0.f;
+        }
+        __syncthreads();
+        if (!act) continue;
+        for (int ii = 0; ii < RA_KT && i0 + ii < Tn; ++ii) {
+            const int pr = (RA_KT - 1 - ii) + (int)threadIdx.x;          // (T-1-(i0+ii)+j) - rbase
+            float s = uk, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { s += Qs[ii][e] * kk[e] + (Qs[ii][e] + vbv[e]) * Ps[pr][e]; dp += Gs[ii][e] * vv[e]; }
+            const float p = __expf(s * scale - Ls[ii]);
+            const bool keep = drop.thr == 0u || rng_keep(rng_row_key(drop.key, (uint32_t)(bh * Tn + i0 + ii)), (uint32_t)j, drop.thr);
+            const float pd = keep ? p * drop.scale : 0.f;
+            dp = keep ? dp * drop.scale : 0.f;
+            const float dS = p * (dp - Ds[ii]) * scale;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { ak[e] += dS * (Qs[ii][e] + uu[e]); av[e] += pd * Gs[ii][e]; }
+        }
+    }
+    if (act) {
+        const size_t row = ((size_t)b * Tn + j) * d + h * DH;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) { dk[row + e] = from_f<T>(ak[e]); dv[row + e] = from_f<T>(av[e]); }
+    }
+}
+
+// dposp[r, h*DH ..] += sum over the batch and over the (i, j) pairs with T-1-i+j == r of dS_ij * (q_i + vb): one thread per table row
+template <typename T, int DH>
+__global__ __launch_bounds__(RA_QB) void relattn_bwd_dpos_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const float* __restrict__ posp,
+                                                                 const float* __restrict__ u, const float* __restrict__ vb, const T* __restrict__ dO,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dposp,
+                                                                 int H, int Tn, float scale, DropSpec drop) {
+    __shared__ float Qs[RA_KT][DH + 1], Gs[RA_KT][DH + 1], Ks[RA_KT + RA_QB - 1][DH + 1], Vs[RA_KT + RA_QB - 1][DH + 1], Ls[RA_KT], Ds[RA_KT];
+    const int d = H * DH, bh = blockIdx.y, b = bh / H, h = bh % H, r0 = blockIdx.x * RA_QB, r = r0 + threadIdx.x;
+    const bool act = r < 2 * Tn - 1;
+    float pp[DH], acc[DH], uu[DH], vbv[DH];
+#pragma unroll
+    for (int e = 0; e < DH; ++e) { pp[e] = act ? posp[(size_t)r * d + h * DH + e] : 0.f; acc[e] = 0.f; uu[e] = u[h * DH + e]; vbv[e] = vb[h * DH + e]; }
+    for (int i0 = 0; i0 < Tn; i0 += RA_KT) {
+        // keys: j = i + r - (T-1) for i in [i0, i0+KT), r in [r0, r0+QB): from jbase = i0 + r0 - (T-1)
+        const int jbase = i0 + r0 - (Tn - 1);
+        __syncthreads();
+        for (int x = threadIdx.x; x < RA_KT * DH; x += RA_QB) {
+            const int ii = x / DH, e = x % DH, i = i0 + ii;
+            Qs[ii][e] = i < Tn ? ldf(q + ((size_t)b * Tn + i) * d + h * DH + e) : 0.f;
+            Gs[ii][e] = i < Tn ? ldf(dO + ((size_t)b * Tn + i) * d + h * DH + e) : 0.f;
+        }
+        for (int x = threadIdx.x; x < RA_KT; x += RA_QB) { const int i = i0 + x; Ls[x] = i < Tn ? lse[(size_t)bh * Tn + i] : 0.f; Ds[x] = i < Tn ? delta[(size_t)bh * Tn + i] : 0.f; }
+        for (int x = threadIdx.x; x < (RA_KT + RA_QB - 1) * DH; x += RA_QB) {
+            const int jj = x / DH, e = x % DH, j = jbase + jj;
+            const bool ok = j >= 0 && j < Tn;
+            Ks[jj][e] = ok ? ldf(k + ((size_t)b * Tn + j) * d + h * DH + e) : 0.f;
+            Vs[jj][e] = ok ? ldf(v + ((size_t)b * Tn + j) * d + h * DH + e) : 0.f;
+        }
+        __syncthreads();
+        if (!act) continue;
+        for (int ii = 0; ii < RA_KT && i0 + ii < Tn; ++ii) {
+            const int jl = ii + (int)threadIdx.x, j = jbase + jl;
+            if (j < 0 || j >= Tn) continue;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { s += (Qs[ii][e] + uu[e]) * Ks[jl][e] + (Qs[ii][e] + vbv[e]) * pp[e]; dp += Gs[ii][e] * Vs[jl][e]; }
+            const float p = __expf(s * scale - Ls[ii]);
+            const bool keep = drop.thr == 0u || rng_keep(rng_row_key(drop.key, (uint32_t)(bh * Tn + i0 + ii)), (uint32_t)j, drop.thr);
+            dp = keep ? dp * drop.scale : 0.f;
+            const float dS = p * (dp - Ds[ii]) * scale;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) acc[e] += dS * (Qs[ii][e] + vbv[e]);
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < DH; ++e) atomicAdd(&dposp[(size_t)r * d + h * DH + e], acc[e]);
+    }
+}
+
+#define RA_DISPATCH(KERNEL, TT, grid, s, ...)                                                                           \
+    switch (dh) {                                                                                                       \
+        case 8: hipLaunchKernelGGL((KERNEL<TT, 8>), grid, dim3(RA_QB), 0, s, __VA_ARGS__); break;                        \
+        case 16: hipLaunchKernelGGL((KERNEL<TT, 16>), grid, dim3(RA_QB), 0, s, __VA_ARGS__); break;                      \
+        case 32: hipLaunchKernelGGL((KERNEL<TT, 32>), grid, dim3(RA_QB), 0, s, __VA_ARGS__); break;                      \
+        case 64: hipLaunchKernelGGL((KERNEL<TT, 64>), grid, dim3(RA_QB), 0, s, __VA_ARGS__); break;                      \
+        default: ishara_set_error("relative attention: head dim %d unsupported (8, 16, 32, 64)", dh); return -1;         \
+    }
+
+static int launch_relattn_fwd(int dt, const void* q, const void* k, const void* v, const float* posp, const float* u, const float* vb, void* o, float* lse,
+                              int B, int H, int T, int dh, float scale, DropSpec drop, hipStream_t s) {
+    const dim3 grid((T + RA_QB - 1) / RA_QB, B * H);
+    if (dt == DT_BF16) { RA_DISPATCH(relattn_fwd_kernel, bf16, grid, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, posp, u, vb, (bf16*)o, lse, H, T, scale, drop) }
+    else { RA_DISPATCH(relattn_fwd_kernel, float, grid, s, (const float*)q, (const float*)k, (const float*)v, posp, u, vb, (float*)o, lse, H, T, scale, drop) }
+    return R4_OK();
+}
+static int launch_relattn_bwd(int dt, const void* q, const void* k, const void* v, const float* posp, const float* u, const float* vb, const void* o, const void* dO,
+                              const float* lse, float* delta, void* dq, void* dk, void* dv, float* du, float* dvb, float* dposp,
+                              int B, int H, int T, int dh, float scale, DropSpec drop, hipStream_t s) {
+    const dim3 gq((T + RA_QB - 1) / RA_QB, B * H), gp((2 * T - 1 + RA_QB - 1) / RA_QB, B * H);
+    if (dt == DT_BF16) {
+        RA_DISPATCH(relattn_bwd_dq_kernel, bf16, gq, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, posp, u, vb, (const bf16*)o, (const bf16*)dO, lse, delta, (bf16*)dq, du, dvb, H, T, scale, drop)
+        RA_DISPATCH(relattn_bwd_dkv_kernel, bf16, gq, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, posp, u, vb, (const bf16*)dO, lse, (const float*)delta, (bf16*)dk, (bf16*)dv, H, T, scale, drop)
+        RA_DISPATCH(relattn_bwd_dpos_kernel, bf16, gp, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, posp, u, vb, (const bf16*)dO, lse, (const float*)delta, dposp, H, T, scale, drop)
+    } else {
+        RA_DISPATCH(relattn_bwd_dq_kernel, float, gq, s, (const float*)q, (const float*)k, (const float*)v, posp, u, vb, (const float*)o, (const float*)dO, lse, delta, (float*)dq, du, dvb, H, T, scale, drop)
+        RA_DISPATCH(relattn_bwd_dkv_kernel, float, gq, s, (const float*)q, (const float*)k, (const float*)v, posp, u, vb, (const float*)dO, lse, (const float*)delta, (float*)dk, (float*)dv, H, T, scale, drop)
+        RA_DISPATCH(relattn_bwd_dpos_kernel, float, gp, s, (const float*)q, (const float*)k, (const float*)v, posp, u, vb, (const float*)dO, lse, (const float*)delta, dposp, H, T, scale, drop)
+    }
+    return R4_OK();
+}
+
+// ------------------------------------------------------------------ construction
+static DenseW r4_dense(ishara_model* m, const std::string& wname, const std::string& bname, int K, int N) {
+    DenseW w; w.K = K; w.N = N;
+    w.w = m->addp(wname, K, N, true);
+    if (!bname.empty()) w.b = m->addp(bname, N, 0, true);
+    return w;
+}
+static Norm r4_norm(ishara_model* m, const std::string& p, int c) {
+    Norm n; n.gamma = m->addp(p + ".weight", c, 0, true); n.beta = m->addp(p + ".bias", c, 0, true);
+    return n;
+}
+static R5FFN r4_build_ffn(ishara_model* m, const std::string& mod, const std::string& ln, float factor) {
+    R5FFN f;
+    const int d = m->d, e = m->cfg.expansion_factor;
+    f.W1 = r4_dense(m, mod + ".sequential.0.weight", mod + ".sequential.0.bias", d, d * e);
+    f.W2 = r4_dense(m, mod + ".sequential.3.weight", mod + ".sequential.3.bias", d * e, d);
+    f.ln = r4_norm(m, ln, d);
+    f.site_in = m->nsites++; f.site_out = m->nsites++;
+    f.factor = factor;
+    return f;
+}
+
+int r4_validate(const ishara_config& c) {
+    if (c.num_conv_conform_blocks <= 0) { ishara_set_error("SqueezeformerEncoder: num_layers (num_conv_conform_blocks) must be > 0"); return -1; }
+    if (c.features < 7) { ishara_set_error("SqueezeformerEncoder: input_dim (features) must be >= 7 (two 3x3 stride-2 convolutions)"); return -1; }
+    if (c.frames < 7) { ishara_set_error("SqueezeformerEncoder: frames must be >= 7"); return -1; }
+    const int dh = c.dim / c.num_heads;
+    if (dh != 8 && dh != 16 && dh != 32 && dh != 64) { ishara_set_error("SqueezeformerEncoder: head dim %d unsupported (8, 16, 32, 64)", dh); return -1; }
+    const int L = c.num_conv_conform_blocks;
+    if (c.reduce_layer_index < L && c.recover_layer_index < L && c.recover_layer_index <= c.reduce_layer_index) { ishara_set_error("SqueezeformerEncoder: recover_layer_index must follow reduce_layer_index"); return -1; }
+    if (c.reduce_layer_index >= L && c.recover_layer_index < L) { ishara_set_error("SqueezeformerEncoder: recover without reduce"); return -1; }
+    if (c.reduce_layer_index < 0 || c.recover_layer_index < 0) { ishara_set_error("SqueezeformerEncoder: negative layer index"); return -1; }
+    return 0;
+}
+
+void r4_build_graph(ishara_model* m) {
+    R4State* S = new R4State();
+    m->r4 = S;
+    const ishara_config& c = m->cfg;
+    const int d = m->d, L = c.num_conv_conform_blocks, k = c.transformer_kernel_size;
+    S->T0 = c.frames; S->F = c.features;
+    S->T1 = (S->T0 - 3) / 2 + 1; S->F1 = (S->F - 3) / 2 + 1;
+    S->T2 = (S->T1 - 3) / 2 + 1; S->F2 = (S->F1 - 3) / 2 + 1;
+    S->reduce = c.reduce_layer_index < L ? c.reduce_layer_index : L;
+    S->recover = c.recover_layer_index < L ? c.recover_layer_index : L;
+    S->T3 = (S->T2 - 3) / 2 + 1; S->Fr = (d - 1) / 2; S->Kp = (int)rup(S->Fr, 8); S->Trec = 2 * S->T3;
+    S->w1 = m->addp("conv_subsample.sequential.0.weight", d, 9, true); S->b1 = m->addp("conv_subsample.sequential.0.bias", d, 0, true);
+    S->w2 = m->addp("conv_subsample.sequential.2.conv.weight", d, 9, true); S->b2 = m->addp("conv_subsample.sequential.2.conv.bias", d, 0, true);
+    S->Win = r4_dense(m, "input_proj.0.weight", "input_proj.0.bias", d * S->F2, d);
+    S->site_in = m->nsites++;
+    S->trw = m->addp("time_reduction_layer.sequential.0.conv.weight", 9, 0, true); S->trb = m->addp("time_reduction_layer.sequential.0.conv.bias", 1, 0, true);
+    S->Wred = r4_dense(m, "time_reduction_proj.weight", "time_reduction_proj.bias", S->Fr, d);
+    S->Wrec = r4_dense(m, "time_recover_layer.weight", "time_recover_layer.bias", d, d);
+    const float factor = c.half_step_residual ? 0.5f : 1.0f;
+    int Tl = S->T2;
+    for (int idx = 0; idx < L; ++idx) {
+        if (idx == S->reduce) Tl = S->T3;
+        if (idx == S->recover) Tl = S->Trec;
+        R4Layer Ly;
+        Ly.T = Tl;
+        Ly.wrapped = idx >= S->reduce && idx < S->recover;
+        const std::string s = "layers." + std::to_string(idx) + (Ly.wrapped ? ".module" : "") + ".sequential";
+        const std::string a = s + ".0.module.attention";
+        RelMHSA& A = Ly.mha;
+        A.u = m->addp(a + ".u_bias", d, 0, true); A.v = m->addp(a + ".v_bias", d, 0, true);
+        A.Wq = r4_dense(m, a + ".query_proj.weight", a + ".query_proj.bias", d, d);
+        A.Wk = r4_dense(m, a + ".key_proj.weight", a + ".key_proj.bias", d, d);
+        A.Wv = r4_dense(m, a + ".value_proj.weight", a + ".value_proj.bias", d, d);
+        A.Wpos = r4_dense(m, a + ".pos_proj.weight", "", d, d);
+        A.Wo = r4_dense(m, a + ".out_proj.weight", a + ".out_proj.bias", d, d);
+        A.ln = r4_norm(m, s + ".1", d);
+        A.site_attn = m->nsites++; A.site_out = m->nsites++;
+        Ly.ffn1 = r4_build_ffn(m, s + ".2.module", s + ".3", factor);
+        ConfConv& cv = Ly.conv;
+        const std::string cs = s + ".4.module.sequential";
+        cv.k = k; cv.bn_eps = R4_EPS; cv.ln_eps = R4_EPS; cv.bn_keep = 0.9f; cv.bn_unbiased = 1; cv.swish_after_bn = 1; cv.has_out_drop = 1;
+        cv.Wp1 = r4_dense(m, cs + ".1.conv.weight", cs + ".1.conv.bias", d, 2 * d);
+        cv.dw = m->addp(cs + ".3.conv.weight", k, d, true);
+        cv.dwb = -1;
+        cv.bn.gamma = m->addp(cs + ".4.weight", d, 0, true); cv.bn.beta = m->addp(cs + ".4.bias", d, 0, true);
+        cv.bn.mm = m->addp(cs + ".4.running_mean", d, 0, false); cv.bn.mv = m->addp(cs + ".4.running_var", d, 0, false);
+        cv.Wp2 = r4_dense(m, cs + ".6.conv.weight", cs + ".6.conv.bias", d, d);
+        cv.site_out = m->nsites++;
+        cv.ln = r4_norm(m, s + ".5", d);
+        Ly.ffn2 = r4_build_ffn(m, s + ".6.module", s + ".7", factor);
+        // the table this layer's length needs
+        int pe = -1;
+        for (size_t t = 0; t < S->pe_T.size(); ++t) if (S->pe_T[t] == Tl) pe = (int)t;
+        if (pe < 0) { pe = (int)S->pe_T.size(); S->pe_T.push_back(Tl); }
+        Ly.pe = pe;
+        S->layers.push_back(Ly);
+        m->layer_entry_end.push_back(m->entries.size());
+    }
+    S->Tout = Tl;
+    int64_t off = 0;
+    for (auto& e : m->entries) if (e.trainable) { e.offset = off; off += e.shape[0] * (e.ndim == 2 ? e.shape[1] : 1); }
+    m->n_train = off;
+    for (auto& e : m->entries) if (!e.trainable) { e.offset = off; off += e.shape[0] * (e.ndim == 2 ? e.shape[1] : 1); }
+    m->n_total = off;
+    m->bucket_lo.push_back(0); m->bucket_hi.push_back(m->n_train);
+    m->bucket_after_layer.assign(S->layers.size(), -1);
+    // R2: RelPositionalEncoding rows for T frames (modules.py:73-108): row r = relative position T-1-r, even columns sin, odd cos
+    for (int T : S->pe_T) {
+        std::vector<float> tab((size_t)(2 * T - 1) * d);
+        for (int r = 0; r < 2 * T - 1; ++r) {
+            const float pos = (float)(T - 1 - r);
+            for (int i = 0; i < d; i += 2) {
+                const float div = expf((float)i * -(logf(10000.0f) / (float)d));
+                tab[(size_t)r * d + i] = sinf(pos * div);
+                if (i + 1 < d) tab[(size_t)r * d + i + 1] = cosf(pos * div);
+            }
+        }
+        S->pe_host.push_back(tab);
+    }
+}
+
+void r4_plan_workspace(ishara_model* m) {
+    R4State* S = m->r4;
+    const int d = m->d, B = m->Bmax, de = d * m->cfg.expansion_factor;
+    const size_t es = dt_size(m->dt);
+    const int Tmax = S->T2 > S->Trec ? S->T2 : S->Trec;
+    m->cur = 0;
+    m->shadow_begin = m->cur;
+    plan_shadow(m, S->Win); plan_shadow(m, S->Wred, S->Kp); plan_shadow(m, S->Wrec);
+    for (auto& L : S->layers)
+        for (DenseW* w : {&L.mha.Wq, &L.mha.Wk, &L.mha.Wv, &L.mha.Wpos, &L.mha.Wo, &L.ffn1.W1, &L.ffn1.W2, &L.conv.Wp1, &L.conv.Wp2, &L.ffn2.W1, &L.ffn2.W2}) plan_shadow(m, *w);
+    m->shadow_end = m->cur;
+    m->shadow_tab_off = m->alloc(m->denses.size() * sizeof(ShadowDesc)).off;
+    S->y1 = m->f32((size_t)B * d * S->T1 * S->F1); S->dz1 = m->f32((size_t)B * d * S->T1 * S->F1);
+    S->sub = m->alloc((size_t)B * S->T2 * d * S->F2 * es); S->dsub = m->alloc((size_t)B * S->T2 * d * S->F2 * es);
+    S->h0 = m->alloc((size_t)B * S->T2 * d * es);
+    S->trpre = m->f32((size_t)B * S->T3 * S->Fr); S->trout = m->alloc((size_t)B * S->T3 * S->Kp * es); S->red = m->alloc((size_t)B * S->T3 * d * es);
+    S->rep = m->alloc((size_t)B * S->Trec * d * es); S->crop = m->alloc((size_t)B * S->Trec * d * es); S->rec = m->alloc((size_t)B * S->Trec * d * es);
+    S->gskip = m->alloc((size_t)B * S->T2 * d * es); S->gwrap = m->alloc((size_t)B * Tmax * d * es);
+    S->dqb = m->alloc((size_t)B * Tmax * d * es); S->dkb = m->alloc((size_t)B * Tmax * d * es); S->dvb = m->alloc((size_t)B * Tmax * d * es);
+    S->dposp = m->f32((size_t)(2 * Tmax - 1) * d);
+    S->dwred = m->f32((size_t)S->Kp * d);
+    for (size_t t = 0; t < S->pe_T.size(); ++t) {
+        S->pe32.push_back(m->f32((size_t)(2 * S->pe_T[t] - 1) * d));
+        S->pedt.push_back(m->alloc((size_t)(2 * S->pe_T[t] - 1) * d * es));
+    }
+    for (auto& L : S->layers) {
+        const size_t Mx = (size_t)B * L.T;
+        auto A = [&](int cols) { return m->alloc(Mx * cols * es); };
+        RelMHSA& a = L.mha;
+        a.q = A(d); a.k = A(d); a.vv = A(d); a.o = A(d); a.lse = m->f32((size_t)B * m->H * L.T); a.posp = m->f32((size_t)(2 * L.T - 1) * d);
+        a.r = A(d); a.mean = m->f32(Mx); a.rstd = m->f32(Mx); a.out = A(d);
+        for (R5FFN* f : {&L.ffn1, &L.ffn2}) { f->za = A(de); f->u = A(de); f->r = A(d); f->mean = m->f32(Mx); f->rstd = m->f32(Mx); f->out = A(d); }
+        ConfConv& c = L.conv;
+        c.g = A(2 * d); c.v = A(d); c.bnv = A(d); c.sw = A(d);
+        c.ssum = m->f32((size_t)B * d); c.ssq = m->f32((size_t)B * d);
+        c.mean = m->f32(d); c.rstd = m->f32(d); c.a = m->f32(d); c.bsh = m->f32(d);
+        c.r = A(d); c.lnmean = m->f32(Mx); c.lnrstd = m->f32(Mx); c.out = A(d);
+        if (L.wrapped) L.wrap_out = A(d);
+    }
+    const size_t Mmax = (size_t)B * Tmax;
+    const int maxw = de > 2 * d ? de : 2 * d;
+    m->gA = m->alloc(Mmax * d * es); m->gB = m->alloc(Mmax * d * es); m->t4 = m->alloc(Mmax * d * es);
+    m->t1 = m->alloc(Mmax * maxw * es); m->t2 = m->alloc(Mmax * maxw * es); m->t3 = m->alloc(Mmax * maxw * es);
+    m->S1 = m->f32((size_t)B * maxw); m->S2 = m->f32((size_t)B * maxw); m->E = m->f32((size_t)B * maxw);
+    m->Fc = m->f32(maxw); m->Ecol = m->f32(maxw); m->fac = m->f32(B);
+    size_t slabf = 0;
+    for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mmax, w->K > S->Kp ? w->K : S->Kp, w->N, m->dt); if (f > slabf) slabf = f; }
+    if (layernorm_bwd_scratch_floats(d) > slabf) slabf = layernorm_bwd_scratch_floats(d);
+    if (dwconv_bwd_scratch_floats(2 * maxw, 31) > slabf) slabf = dwconv_bwd_scratch_floats(2 * maxw, 31);
+    if (dwconv_fwd_scratch_floats(B, Tmax, 2 * maxw) > slabf) slabf = dwconv_fwd_scratch_floats(B, Tmax, 2 * maxw);
+    m->slab = m->f32(slabf);
+    m->delta = m->f32((size_t)B * m->H * Tmax);
+    m->ws_need = m->cur;
+}
+
+int r4_bind(ishara_model* m) {
+    R4State* S = m->r4;
+    for (size_t t = 0; t < S->pe_T.size(); ++t)
+        HIP_CHECK_RET(hipMemcpy(m->ws + S->pe32[t].off, S->pe_host[t].data(), S->pe_host[t].size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> fac((size_t)m->Bmax, m->cfg.half_step_residual ? 0.5f : 1.0f);
+    HIP_CHECK_RET(hipMemcpy(m->ws + m->fac.off, fac.data(), fac.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+void r4_destroy(ishara_model* m) { delete m->r4; m->r4 = nullptr; }
+int r4_output_frames(const ishara_model* m) { return m->r4->Tout; }
+
+// ------------------------------------------------------------------ forward
+static int r4_mhsa_fwd(ishara_model* m, R4State* S, R4Layer& L, const Run& r, const void* x) {
+    RelMHSA& a = L.mha;
+    const int dt = m->dt, d = m->d, T = L.T;
+    OpArgs no; EpiArgs e0;
+    CK(gemm_fwd(m, a.Wq, x, dt, m->W(a.q), dt, r.M, OP_NONE, no, e0));
+    CK(gemm_fwd(m, a.Wk, x, dt, m->W(a.k), dt, r.M, OP_NONE, no, e0));
+    CK(gemm_fwd(m, a.Wv, x, dt, m->W(a.vv), dt, r.M, OP_NONE, no, e0));
+    // pos_proj of the table (the reference repeats the table over the batch, attention.py:135; the projection does not depend on it)
+    CK(gemm_fwd(m, a.Wpos, m->dt == DT_F32 ? (const void*)m->Wf(S->pe32[L.pe]) : (const void*)m->W(S->pedt[L.pe]), dt, m->Wf(a.posp), DT_F32, 2 * T - 1, OP_NONE, no, e0));
+    const float scale = 1.0f / sqrtf((float)m->dh);
+    CKP(m, "relattn_fwd", 4.0 * r.M * d * (double)dt_size(dt), 8.0 * r.B * m->H * (double)T * T * m->dh,
+        launch_relattn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vv), m->Wf(a.posp), m->P(a.u), m->P(a.v), m->W(a.o), m->Wf(a.lse), r.B, m->H, T, m->dh, scale,
+                           dspec(r, a.site_attn, m->cfg.dropout_rate), m->s));
+    EpiArgs ep; ep.resid = x; ep.drop = dspec(r, a.site_out, m->cfg.dropout_rate);
+    CK(gemm_fwd(m, a.Wo, m->W(a.o), dt, m->W(a.r), dt, r.M, OP_NONE, no, ep));
+    return r5_ln_fwd(m, r, m->W(a.r), a.ln, m->W(a.out), a.mean, a.rstd);
+}
+
+// typed launches of the small kernels
+#define R4_TYPED(dt, CALL) do { if ((dt) == DT_BF16) { typedef bf16 TT; CALL; } else { typedef float TT; CALL; } } while (0)
+
+int r4_forward(ishara_model* m, const float* x, int32_t B, float* y, int32_t training, uint32_t seed, hipStream_t st) {
+    R4State* S = m->r4;
+    m->s = st;
+    const int dt = m->dt, d = m->d;
+    OpArgs no;
+    Run r{B, B * S->T2, training, seed};
+    // tables in the storage type (A operand of the pos_proj GEMM)
+    if (dt != DT_F32)
+        for (size_t t = 0; t < S->pe_T.size(); ++t) CK(r5_from_f32(dt, m->Wf(S->pe32[t]), m->W(S->pedt[t]), (size_t)(2 * S->pe_T[t] - 1) * d, m->s));
+    // ---- DepthwiseConv2dSubsampling + input_proj (encoder.py:148-149)
+    hipLaunchKernelGGL(r4_sub1_fwd, dim3(g1d((size_t)B * d * S->T1 * S->F1)), dim3(256), 0, m->s, x, m->P(S->w1), m->P(S->b1), m->Wf(S->y1), B, S->T0, S->F, d, S->T1, S->F1);
+    R4_TYPED(dt, hipLaunchKernelGGL((r4_sub2_fwd<TT>), dim3(g1d((size_t)B * S->T2 * d * S->F2)), dim3(256), 0, m->s, m->Wf(S->y1), m->P(S->w2), m->P(S->b2), m->W<TT>(S->sub), B, d, S->T1, S->F1, S->T2, S->F2));
+    if (R4_OK()) return -2;
+    EpiArgs ein; ein.drop = dspec(r, S->site_in, m->cfg.dropout_rate);
+    CK(gemm_fwd(m, S->Win, m->W(S->sub), dt, m->W(S->h0), dt, r.M, OP_NONE, no, ein));
+    const void* h = m->W(S->h0);
+    const void* recover_src = nullptr;
+    const int keepT = m->T;
+    int Tl = S->T2;
+    for (int idx = 0; idx < (int)S->layers.size(); ++idx) {
+        R4Layer& L = S->layers[idx];
+        if (idx == S->reduce) {            // time reduction (encoder.py:152-155)
+            recover_src = h;
+            R4_TYPED(dt, hipLaunchKernelGGL((r4_tred_fwd<TT>), dim3(g1d((size_t)B * S->T3 * S->Kp)), dim3(256), 0, m->s, (const TT*)h, m->P(S->trw), m->P(S->trb), m->Wf(S->trpre), m->W<TT>(S->trout), B, Tl, d, S->T3, S->Fr, S->Kp));
+            DenseW wp = S->Wred; wp.K = S->Kp;
+            EpiArgs e0;
+            CK(gemm_fwd(m, wp, m->W(S->trout), dt, m->W(S->red), dt, B * S->T3, OP_NONE, no, e0));
+            h = m->W(S->red); Tl = S->T3;
+        }
+        if (idx == S->recover) {           // recover_resolution + Linear + skip (encoder.py:157-162)
+            CK(r4_rows_launch<0>(dt, h, nullptr, m->W(S->rep), B, S->Trec, S->T3, d, m->s));
+            CK(r4_rows_launch<1>(dt, recover_src, nullptr, m->W(S->crop), B, S->Trec, S->T2, d, m->s));
+            EpiArgs er; er.resid = m->W(S->crop);
+            CK(gemm_fwd(m, S->Wrec, m->W(S->rep), dt, m->W(S->rec), dt, B * S->Trec, OP_NONE, no, er));
+            h = m->W(S->rec); Tl = S->Trec;
+        }
+        m->T = Tl;
+        Run rl{B, B * Tl, training, seed};
+        CK(r4_mhsa_fwd(m, S, L, rl, h));
+        CK(r5_ffn_fwd(m, L.ffn1, rl, m->W(L.mha.out)));
+        CK(confconv_fwd(m, L.conv, rl, m->W(L.ffn1.out)));
+        CK(r5_ffn_fwd(m, L.ffn2, rl, m->W(L.conv.out)));
+        const void* out = m->W(L.ffn2.out);
+        if (L.wrapped) { CK(r4_rows_launch<4>(dt, h, out, m->W(L.wrap_out), B, Tl, Tl, d, m->s)); out = m->W(L.wrap_out); }      // ResidualConnectionModule around the block
+        h = out;
+    }
+    m->T = keepT;
+    CK(r5_to_f32(dt, h, y, (size_t)B * S->Tout * d, m->s));
+    m->lastB = B; m->last_training = training; m->last_seed = seed; m->last_x = x;
+    return 0;
+}
+
+// ------------------------------------------------------------------ backward
+static int r4_mhsa_bwd(ishara_model* m, R4State* S, R4Layer& L, const Run& r, const void* x, const void* g, void* gn) {
+    RelMHSA& a = L.mha;
+    const int dt = m->dt, d = m->d, T = L.T;
+    OpArgs no; EpiArgs e0;
+    void* dr = m->W(m->t4);
+    CK(r5_ln_bwd(m, r, g, m->W(a.r), a.ln, a.mean, a.rstd, dr));
+    const void* gs = dr;
+    const DropSpec od = dspec(r, a.site_out, m->cfg.dropout_rate);
+    if (od.thr) {
+        CKP(m, "map_rows", 2.0 * r.M * d * (double)dt_size(dt), 0, launch_map_rows(dt, MAP_DROPMASK, dr, m->W(m->t3), nullptr, od, r.M, T, d, m->s));
+        gs = m->W(m->t3);
+    }
+    CK(gemm_dgrad(m, a.Wo, gs, dt, m->W(m->t1), r.M, OP_NONE, no, e0));                          // d context
+    CK(gemm_wgrad(m, a.Wo, m->W(a.o), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
+    hipLaunchKernelGGL(r4_fill_f32, dim3(g1d((size_t)(2 * T - 1) * d)), dim3(256), 0, m->s, m->Wf(S->dposp), (size_t)(2 * T - 1) * d, 0.f);
+    const float scale = 1.0f / sqrtf((float)m->dh);
+    CKP(m, "relattn_bwd", 12.0 * r.M * d * (double)dt_size(dt), 24.0 * r.B * m->H * (double)T * T * m->dh,
+        launch_relattn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vv), m->Wf(a.posp), m->P(a.u), m->P(a.v), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta),
+                           m->W(S->dqb), m->W(S->dkb), m->W(S->dvb), m->G(a.u), m->G(a.v), m->Wf(S->dposp), r.B, m->H, T, m->dh, scale,
+                           dspec(r, a.site_attn, m->cfg.dropout_rate), m->s));
+    // pos_proj weight gradient: table^T . dposp (no bias, the table itself has no gradient)
+    CK(gemm_wgrad(m, a.Wpos, m->dt == DT_F32 ? (const void*)m->Wf(S->pe32[L.pe]) : (const void*)m->W(S->pedt[L.pe]), dt, OP_NONE, no, m->Wf(S->dposp), DT_F32, OP_NONE, no, 2 * T - 1));
+    // the three input projections: dx = dr + dq Wq^T + dk Wk^T + dv Wv^T
+    EpiArgs e1; e1.resid = dr;
+    CK(gemm_dgrad(m, a.Wq, m->W(S->dqb), dt, m->W(m->t1), r.M, OP_NONE, no, e1));
+    EpiArgs e2; e2.resid = m->W(m->t1);
+    CK(gemm_dgrad(m, a.Wk, m->W(S->dkb), dt, m->W(m->t2), r.M, OP_NONE, no, e2));
+    EpiArgs e3; e3.resid = m->W(m->t2);
+    CK(gemm_dgrad(m, a.Wv, m->W(S->dvb), dt, gn, r.M, OP_NONE, no, e3));
+    CK(gemm_wgrad(m, a.Wq, x, dt, OP_NONE, no, m->W(S->dqb), dt, OP_NONE, no, r.M));
+    CK(gemm_wgrad(m, a.Wk, x, dt, OP_NONE, no, m->W(S->dkb), dt, OP_NONE, no, r.M));
+    CK(gemm_wgrad(m, a.Wv, x, dt, OP_NONE, no, m->W(S->dvb), dt, OP_NONE, no, r.M));
+    return 0;
+}
+
+int r4_backward(ishara_model* m, const float* dy, int32_t B, float* dx, hipStream_t st) {
+    R4State* S = m->r4;
+    m->s = st;
+    const int dt = m->dt, d = m->d;
+    OpArgs no; EpiArgs e0;
+    CK(launch_fill_u32(m->grads, (size_t)m->n_train, 0u, m->s));
+    void* g = m->W(m->gA); void* gn = m->W(m->gB);
+    // gradient of the output in the storage type
+    if (dt != DT_F32) CK(r5_from_f32(dt, dy, g, (size_t)B * S->Tout * d, m->s));
+    else HIP_CHECK_RET(hipMemcpyAsync(g, dy, (size_t)B * S->Tout * d * sizeof(float), hipMemcpyDeviceToDevice, m->s));
+    const int keepT = m->T;
+    bool have_skip = false;
+    // inputs of the layers, as the forward pass chained them
+    std::vector<const void*> lin(S->layers.size());
+    {
+        const void* h = m->W(S->h0);
+        for (int idx = 0; idx < (int)S->layers.size(); ++idx) {
+            if (idx == S->reduce) h = m->W(S->red);
+            if (idx == S->recover) h = m->W(S->rec);
+            lin[idx] = h;
+            h = S->layers[idx].wrapped ? m->W(S->layers[idx].wrap_out) : m->W(S->layers[idx].ffn2.out);
+        }
+    }
+#define SWAP() do { void* _t = g; g = gn; gn = _t; } while (0)
+    for (int idx = (int)S->layers.size() - 1; idx >= 0; --idx) {
+        R4Layer& L = S->layers[idx];
+        const int Tl = L.T;
+        m->T = Tl;
+        Run rl{B, B * Tl, 1, m->last_seed};
+        if (L.wrapped) HIP_CHECK_RET(hipMemcpyAsync(m->W(S->gwrap), g, (size_t)rl.M * d * dt_size(dt), hipMemcpyDeviceToDevice, m->s));   // the skip branch of the wrapper
+        CK(r5_ffn_bwd(m, L.ffn2, rl, m->W(L.conv.out), g, gn)); SWAP();
+        CK(confconv_bwd(m, L.conv, rl, m->W(L.ffn1.out), g, gn)); SWAP();
+        CK(r5_ffn_bwd(m, L.ffn1, rl, m->W(L.mha.out), g, gn)); SWAP();
+        CK(r4_mhsa_bwd(m, S, L, rl, lin[idx], g, gn)); SWAP();
+        if (L.wrapped) { CK(r4_rows_launch<4>(dt, m->W(S->gwrap), g, gn, B, Tl, Tl, d, m->s)); SWAP(); }
+        if (idx == S->recover) {           // g = gradient of rec = Linear(rep) + crop(recover_src)
+            CK(r4_rows_launch<3>(dt, g, nullptr, m->W(S->gskip), B, S->T2, S->Trec, d, m->s));        // into the longer pre-reduction sequence
+            have_skip = true;
+            CK(gemm_dgrad(m, S->Wrec, g, dt, m->W(m->t1), B * S->Trec, OP_NONE, no, e0));
+            CK(gemm_wgrad(m, S->Wrec, m->W(S->rep), dt, OP_NONE, no, g, dt, OP_NONE, no, B * S->Trec));
+            CK(r4_rows_launch<2>(dt, m->W(m->t1), nullptr, gn, B, S->T3, S->Trec, d, m->s)); SWAP();
+        }
+        if (idx == S->reduce) {            // g = gradient of red = Linear(swish(conv3x3(h)))
+            DenseW wp = S->Wred; wp.K = S->Kp;
+            CK(gemm_dgrad(m, wp, g, dt, m->W(m->t1), B * S->T3, OP_NONE, no, e0));                    // d trout [B*T3, Kp]
+            // weight gradient over the padded K (the pad columns of trout are zero, so are the rows >= Fr of the product): into a [Kp, d]
+            // scratch, then the Fr real rows are added to the parameter's gradient
+            hipLaunchKernelGGL(r4_fill_f32, dim3(g1d((size_t)S->Kp * d)), dim3(256), 0, m->s, m->Wf(S->dwred), (size_t)S->Kp * d, 0.f);
+            CKP(m, "wgrad(time_reduction_proj)", 0, 0, launch_gemm_tn(dt, dt, dt, OP_NONE, OP_NONE, m->W(S->trout), g, m->Wf(S->dwred), m->G(S->Wred.b), m->Wf(m->slab), B * S->T3, S->Kp, d, no, no, m->s));
+            hipLaunchKernelGGL(r4_axpy_f32, dim3(g1d((size_t)S->Fr * d)), dim3(256), 0, m->s, m->Wf(S->dwred), m->G(S->Wred.w), (size_t)S->Fr * d);
+            const void* hprev = idx > 0 ? (S->layers[idx - 1].wrapped ? m->W(S->layers[idx - 1].wrap_out) : m->W(S->layers[idx - 1].ffn2.out)) : m->W(S->h0);
+            R4_TYPED(dt, hipLaunchKernelGGL((r4_tred_bwd_w<TT>), dim3(64), dim3(256), 0, m->s, (const TT*)m->W(m->t1), m->Wf(S->trpre), (const TT*)hprev, m->G(S->trw), m->G(S->trb), B, S->T2, d, S->T3, S->Fr, S->Kp));
+            R4_TYPED(dt, hipLaunchKernelGGL((r4_tred_bwd_x<TT>), dim3(g1d((size_t)B * S->T2 * d)), dim3(256), 0, m->s, (const TT*)m->W(m->t1), m->Wf(S->trpre), m->P(S->trw),
+                                            have_skip ? (const TT*)m->W(S->gskip) : (const TT*)nullptr, (TT*)gn, B, S->T2, d, S->T3, S->Fr, S->Kp));
+            SWAP();
+        }
+    }
+#undef SWAP
+    m->T = keepT;
+    // ---- input_proj and the convolution subsampling
+    Run r0{B, B * S->T2, 1, m->last_seed};
+    const void* gs = g;
+    const DropSpec din = dspec(r0, S->site_in, m->cfg.dropout_rate);
+    if (din.thr) {
+        CKP(m, "map_rows", 2.0 * r0.M * d * (double)dt_size(dt), 0, launch_map_rows(dt, MAP_DROPMASK, g, gn, nullptr, din, r0.M, S->T2, d, m->s));
+        gs = gn;
+    }
+    CK(gemm_wgrad(m, S->Win, m->W(S->sub), dt, OP_NONE, no, gs, dt, OP_NONE, no, r0.M));
+    CK(gemm_dgrad(m, S->Win, gs, dt, m->W(S->dsub), r0.M, OP_NONE, no, e0));
+    float* dz1 = m->Wf(S->dz1);
+    R4_TYPED(dt, hipLaunchKernelGGL((r4_sub2_bwd_w<TT>), dim3(d), dim3(256), 0, m->s, (const TT*)m->W(S->dsub), (const TT*)m->W(S->sub), m->Wf(S->y1), m->G(S->w2), m->G(S->b2), B, d, S->T1, S->F1, S->T2, S->F2));
+    R4_TYPED(dt, hipLaunchKernelGGL((r4_sub2_bwd_x<TT>), dim3(g1d((size_t)B * d * S->T1 * S->F1)), dim3(256), 0, m->s, (const TT*)m->W(S->dsub), (const TT*)m->W(S->sub), m->P(S->w2), m->Wf(S->y1), dz1, B, d, S->T1, S->F1, S->T2, S->F2));
+    hipLaunchKernelGGL(r4_sub1_bwd_w, dim3(d), dim3(256), 0, m->s, dz1, m->last_x, m->G(S->w1), m->G(S->b1), B, S->T0, S->F, d, S->T1, S->F1);
+    if (dx) hipLaunchKernelGGL(r4_sub1_bwd_x, dim3(g1d((size_t)B * S->T0 * S->F)), dim3(256), 0, m->s, dz1, m->P(S->w1), dx, B, S->T0, S->F, d, S->T1, S->F1);
+    if (R4_OK()) return -2;
+    if (!m->bucket_ev.empty()) HIP_CHECK_RET(hipEventRecord(m->bucket_ev.back(), m->s));
+    return 0;
+}

@@ -1,8 +1,10 @@
 """CPU restatement of the reference's torch Squeezeformer family — TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: `/root/reference/squeezeformer/*` does not import as shipped (`modules.py:21` imports a module the package
-lacks) and the reference holds no vectors for it, so this restatement is checked only against itself (two
-formulations of the relative shift, torch autograd for every gradient) — it follows the files line by line:
+PARITY PINNED by vectors produced by running the reference's own files: oracle/gen_golden_squeezeformer.py loads
+`/root/reference/squeezeformer/{attention,modules,convolution,encoder}.py` in the build container (the package `__init__` is bypassed
+and the missing `squeezeformer.activation.Swish` is satisfied by the `Swish` class convolution.py:22-27 itself defines) and writes
+tests/golden/squeezeformer_r4.npz; tests/test_golden_squeezeformer.py checks every function below against it (sub-module outputs,
+per-layer outputs, training-mode output, autograd gradients, BatchNorm statistics).  It follows the files line by line:
 
   R1  RelativeMultiHeadAttention            squeezeformer/attention.py:25-110   (`_relative_shift` :102-110)
       MultiHeadedSelfAttentionModule         attention.py:113-139
