@@ -186,8 +186,9 @@ DEVI void mma_tile(const char* ldsA, const char* ldsB, int wr, int wc, int lane,
 template <typename TC>
 DEVI void epilogue_chunk(float (&v)[8], int m, int n, int nv, int N, const EpiArgs& ea, TC* __restrict__ C) {
     if (ea.bias) {
+        const float bs = (ea.rowscale && ea.rowscale_bias) ? ea.rowscale[m / ea.T] : 1.f;      // row scale folded into the A operand: bias only
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nv) v[e] += ea.bias[n + e];
+        for (int e = 0; e < 8; ++e) if (e < nv) v[e] += ea.bias[n + e] * bs;
     }
     if (ea.addtab) {
         const float* t = ea.addtab + (size_t)(m % ea.tab_period) * N + n;
@@ -212,7 +213,7 @@ DEVI void epilogue_chunk(float (&v)[8], int m, int n, int nv, int N, const EpiAr
             v[e + 1] = (h >> 16) >= ea.drop.thr ? v[e + 1] * ea.drop.scale : 0.f;
         }
     }
-    if (ea.rowscale) {
+    if (ea.rowscale && !ea.rowscale_bias) {
         const float s = ea.rowscale[m / ea.T];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= s;
@@ -304,8 +305,9 @@ struct EpiRows {
                 continue;
             }
             const bool ok = m[q] < M;
+            const float bs = (ea.rowscale && ea.rowscale_bias) ? rs[q] : 1.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bias[e];
+            for (int e = 0; e < 8; ++e) v[e] += bias[e] * bs;
             if (ea.pre_out && ok) store8(reinterpret_cast<TC*>(ea.pre_out) + off[q], v);
             if (ea.act == ACT_SWISH) {
 #pragma unroll
@@ -323,7 +325,7 @@ struct EpiRows {
             v[e + 1] = (h >> 16) >= ea.drop.thr ? v[e + 1] * ea.drop.scale : 0.f;
         }
             }
-            if (ea.rowscale) {
+            if (ea.rowscale && !ea.rowscale_bias) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= rs[q];
             }
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_t_kernel(const TM* __restrict_
                     if (n >= N) continue;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bias[j][e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[j][i][e] + bias[j][e] * ((ea.rowscale && ea.rowscale_bias) ? rsc : 1.f);
                     if (ea.addtab) {
                         float t4[4];
                         load4(ea.addtab + (size_t)(m % ea.tab_period) * N + n, t4);
@@ -862,7 +864,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_t_kernel(const TM* __restrict_
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = rng_keep(rk, (uint32_t)(n + e), ea.drop.thr) ? v[e] * ea.drop.scale : 0.f;
                     }
-                    if (ea.rowscale) {
+                    if (ea.rowscale && !ea.rowscale_bias) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] *= rsc;
                     }
@@ -1214,10 +1216,13 @@ DEVI void tr_wait(TrFrags& f) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]));
 }
 
-template <int DBG>      // DBG = 1: the ablation bits of tools/gemm_ablate.py are honoured (kept out of the production loop)
+template <int DBG, bool BRS = false>      // DBG = 1: the ablation bits of tools/gemm_ablate.py are honoured (kept out of the production loop); BRS: weighted bias sum
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                          float* __restrict__ out, float* __restrict__ dbias,
-                                                         int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, int dbg) {
+                                                         int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, int dbg,
+                                                         const float* __restrict__ brs, int brsT) {
+    // brs != nullptr: the bias gradient is the column sum of brs[m / brsT] * B[m,:] (drop-path scale of the sample a row belongs to;
+    // brsT % 32 == 0, so the 32 rows of a stage share it)
     // slab layout: [split][Ka*Nb weight partial | Nb bias partial] so that ONE reduction launch sums both
     const size_t sstride = (size_t)Ka * Nb + Nb;
     __shared__ __attribute__((aligned(16))) char smem[TR_NSTAGE * TR_STAGE];
@@ -1246,6 +1251,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    // weighted bias sum: csum collects the rows of the current sample; at a sample boundary (every brsT / 32 stages) it is folded into
+    // ctot with that sample's scale — one scalar load per sample instead of one per stage (a scalar load in the step loop shares
+    // lgkmcnt with the fragment reads and stalls them)
+    float ctot[4] = {0.f, 0.f, 0.f, 0.f};
+    const int seg_stages = BRS ? brsT / TR_ROWS : 0;
+    int seg_left = BRS ? seg_stages - (m_beg % brsT) / TR_ROWS : -1;
+    int seg_sample = BRS ? m_beg / brsT : 0;
 
     // Software pipeline over the 32-row stages (ring of 4 x 16 KB, slots addressed statically: the loop is unrolled by 4):
     // at step mc the MFMAs of stage mc run from fragments already in registers while the transposing LDS reads of stage
@@ -1328,6 +1340,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         TN_ISSUE(U, mc + (U) + TR_NSTAGE)                                                                                \
         if ((FULL || mc + (U) + 1 < nmc_run) && !no_frag) tr_read_asm<((U) + 1) & 3>(fa, fb, NXT);                       \
         TN_COMPUTE(CUR)                                                                                                  \
+        if (BRS && want_bias && --seg_left == 0) {                                                                       \
+            const float sc = brs[seg_sample];                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) { ctot[j] += sc * csum[j]; csum[j] = 0.f; }                    \
+            seg_left = seg_stages; ++seg_sample;                                                                         \
+        }                                                                                                  \
         tr_wait(NXT);                                                                                                    \
     }
 
@@ -1374,6 +1391,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         }
     }
     if (want_bias) {   // lane (g, c) holds the sum over rows 8g..8g+7 (mod 32) of column 16j + c: fold the 4 row groups
+        if (BRS) {      // the rows of the last, unfinished sample of this split
+            const float sc = seg_left != seg_stages && seg_sample * brsT < M ? brs[seg_sample] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csum[j] = ctot[j] + sc * csum[j];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float t = csum[j];
@@ -1513,7 +1535,8 @@ int g_force_tn_regstage = 0;   // tests: force the register-transposing TN kerne
 int g_tn_blocks = 0;
 int g_tn_phase = 0;            // 0: GEMM + slab sums; 1: GEMM kernel only; 2: slab sums only (the model profiles the two separately)
 
-static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s, int ka_valid, int nb_valid) {
+static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s, int ka_valid, int nb_valid,
+                     const float* brs, int brsT) {
     const int tiles = (Ka / 128) * (Nb / 128);
     // workgroups: one per CU for up to 8 tiles (same kernel time as two per CU, half the slab bytes: the slab sums go
     // 9.6 -> 7.3 us), two per CU for 12+ tiles (N = 768: 61 vs 72 us); g_tn_blocks != 0 overrides (tools/tn_ablate.py)
@@ -1529,8 +1552,9 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
     float* bias_slab = dbias ? slab + (size_t)Ka * Nb : nullptr;        // bias partials sit right behind each split's weight partial
     if (g_tn_phase != 2)
     {
-        if (g_dbg_tn) hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn);
-        else hipLaunchKernelGGL(gemm_tn_tr_kernel<0>, dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0);
+        if (g_dbg_tn) hipLaunchKernelGGL((gemm_tn_tr_kernel<1, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn, brs, brsT);
+        else if (brs && bias_slab) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, true>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT);
+        else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT);
     }
     if (g_tn_phase != 1)
         launch_reduce_slabs2(slab, out, ka_valid * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s, nb_valid ? Nb : 0, nb_valid);   // rows >= ka_valid of A / columns >= nb_valid of B are zero padding
@@ -1556,10 +1580,15 @@ static int run_tn(int opA, int opB, const void* A, const void* B, float* out, fl
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+bool gemm_tn_bias_rowscale_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, int T) {
+    return dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && M % 64 == 0 && Ka % 128 == 0 && Nb % 128 == 0 && M >= 256 && !g_force_tn_regstage && T > 0 && T % 32 == 0;
+}
+
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
-                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid, int nb_valid) {
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid, int nb_valid, const float* bias_rowscale, int bias_T) {
     if (M <= 0 || Ka <= 0 || Nb <= 0) { ishara_set_error("gemm_tn: bad shape"); return -1; }
+    if (bias_rowscale && !gemm_tn_bias_rowscale_ok(dtA, dtB, dtM, M, Ka, Nb, bias_T)) { ishara_set_error("gemm_tn: bias row scale needs the transposed-read kernel and T %% 32 == 0"); return -1; }
     if (ka_valid <= 0) ka_valid = Ka;
     if (nb_valid >= Nb || nb_valid < 0) nb_valid = 0;
     if (nb_valid % 4 != 0) { ishara_set_error("gemm_tn: nb_valid %d must be a multiple of 4", nb_valid); return -1; }
@@ -1572,7 +1601,7 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
         M >= 256 && !g_force_tn_regstage)
     {
         if (ka_valid < Ka && dbias) { ishara_set_error("gemm_tn: padded A columns with a bias gradient"); return -1; }
-        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid, nb_valid);
+        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid, nb_valid, bias_rowscale, bias_T);
     }
     if (ka_valid != Ka || nb_valid) { ishara_set_error("gemm_tn: padded A columns need the bf16 transposed-read kernel (M %% 64, Ka %% 128, Nb %% 128)"); return -1; }
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<bf16, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);

@@ -257,12 +257,13 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
                 if (!full && m >= M) continue;
                 const size_t off = eoff[i] + n0 + 4 * GW * q;          // = m*N + n
                 float v[GW];
+                const float bsc = (f_rowscale && ea.rowscale_bias) ? rsc[i] : 1.f;       // drop-path folded into the A operand: only the bias is scaled
                 if constexpr (PAIR) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = acc[0][i][e] + bias[e]; v[4 + e] = acc[1][i][e] + bias[4 + e]; }
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[0][i][e] + bias[e] * bsc; v[4 + e] = acc[1][i][e] + bias[4 + e] * bsc; }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[q][i][e] + bias[e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[q][i][e] + bias[e] * bsc;
                 }
                 if (f_addtab) {
                     const float* tp = ea.addtab + (size_t)(m % ea.tab_period) * N + n;
@@ -287,7 +288,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
                 if (f_drop) {
                     rng_apply<GW>(rk[i], (uint32_t)n, ea.drop.thr, ea.drop.scale, v);        // n is a multiple of GW
                 }
-                if (f_rowscale) {
+                if (f_rowscale && !ea.rowscale_bias) {
 #pragma unroll
                     for (int e = 0; e < GW; ++e) v[e] *= rsc[i];
                 }
@@ -363,7 +364,7 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
     if (!c_bf16) return mask == 0 ? 0 : AS_ALL;
     if (K == 128) return (mask == AS_DACT || mask == (AS_DACT | AS_DROP)) ? mask : AS_ALL;      // K = 128: the classifier's dgrad only
     switch (mask) {
-        case 0: case AS_RESID: case AS_RESID | AS_ROWSCALE: case AS_RESID | AS_DROP: case AS_ACT | AS_PREOUT: case AS_ACT | AS_PREOUT | AS_DROP:
+        case 0: case AS_RESID: case AS_RESID | AS_ROWSCALE: case AS_ROWSCALE: case AS_RESID | AS_DROP: case AS_ACT | AS_PREOUT: case AS_ACT | AS_PREOUT | AS_DROP:
         case AS_ACT | AS_DROP: case AS_ACT: case AS_DACT: case AS_DACT | AS_DROP: case AS_QKV: case AS_ADDTAB: return mask;
         default: return AS_ALL;
     }
@@ -391,6 +392,7 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
                 break;
             case AS_RESID: AS_LAUNCH(AS_RESID); break;                                           // W2 / Wb / Wp eval, dgrad + skip gradient
             case AS_RESID | AS_ROWSCALE: AS_LAUNCH(AS_RESID | AS_ROWSCALE); break;               // conv block W2 with drop-path
+            case AS_ROWSCALE: AS_LAUNCH(AS_ROWSCALE); break;                                     // its dgrad: (g W2^T) * drop-path scale
             case AS_RESID | AS_DROP: AS_LAUNCH(AS_RESID | AS_DROP); break;                       // Wb / Wp with output dropout
             case AS_ACT | AS_PREOUT: AS_LAUNCH(AS_ACT | AS_PREOUT); break;                       // FFN Wa eval
             case AS_ACT | AS_PREOUT | AS_DROP: AS_LAUNCH(AS_ACT | AS_PREOUT | AS_DROP); break;   // FFN Wa training

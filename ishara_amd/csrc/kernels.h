@@ -30,6 +30,7 @@ struct EpiArgs {
     DropSpec drop = {0, 0, 1.f};      // elementwise inverted dropout (row=m, col=n)
     const float* rowscale = nullptr;  // *= rowscale[m / T]
     int T = 1;
+    int rowscale_bias = 0;            // 1: the row scale multiplies the BIAS only (the A operand already carries it): acc + bias * rowscale[m / T]
     int dact = DACT_NONE;             // *= act'(aux[m,n])
     const void* aux = nullptr;        // TC, [M,N]
     const void* resid = nullptr;      // TC, [M,N]
@@ -49,12 +50,15 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
 // dbias[Nb] += colsum(opB(B)) when dbias != nullptr.  slab = fp32 scratch of
 // gemm_tn_slab_floats(...) floats.
 size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM);
+bool gemm_tn_bias_rowscale_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, int T);   // the transposed-read kernel takes the call and T % 32 == 0
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
-                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0, int nb_valid = 0);   // ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0, int nb_valid = 0,
+                   const float* bias_rowscale = nullptr, int bias_T = 0);   // bias_rowscale: dbias = sum_m bias_rowscale[m / bias_T] * B[m,:] (gemm_tn_bias_rowscale_ok shapes only); ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
 // xb[M, Kp] (bf16) = x[M, F] (f32), zero padded to Kp columns (F % 4 == 0, Kp % 8 == 0)
 int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s);
 
+bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);   // gemm_as.hip: the A-stationary kernel takes this shape
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
 extern int g_force_tn_regstage;   // tests: 1 forces the register-transposing TN kernel
 extern int g_tn_phase;   // 0 GEMM + slab sums, 1 GEMM kernel only, 2 slab sums only
@@ -106,7 +110,7 @@ int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count,
                                                                                                                        // entering moving_var (torch: n/(n-1))
 // ECA fwd on [B,C]: g = a*gap/T + b ; s = sigmoid(conv5(g)) ; P = a*s ; Q = b*s
 int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
-                   float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s);
+                   float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, const float* rs = nullptr);   // rs: P, Q additionally scaled by rs[b] (drop-path folded into the affine)
 // y = x*P[b,c] + Q[b,c] (+ resid)    (P,Q per sample) ; if Q == nullptr -> no offset
 int launch_sample_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y,
                          int B, int T, int C, hipStream_t s);

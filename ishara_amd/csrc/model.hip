@@ -3,6 +3,7 @@
 // forward / backward / optimizer orchestration over the kernels in gemm.hip, elementwise.hip,
 // attention.hip, ctc.hip and optimizer.hip.  Everything is launched on the caller's stream.
 #include "model_types.h"
+extern int g_force_regstage;
 #include <algorithm>
 #include <stdlib.h>
 
@@ -471,13 +472,14 @@ int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* 
     CKP(m, gemm_nt_kernel_name(dtA, m->dt, m->dt, aop, dY, M, w.K, w.N, w.ldn, ea), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
     return 0;
 }
-int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid, int nb_valid) {
+int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid, int nb_valid,
+               const float* bias_rowscale, int bias_T) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
     // the GEMM kernel and the sums of its split-M slabs are profiled under separate keys (the kernel's key is its rocprof name)
     g_tn_phase = 1;
-    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid));
+    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T));
     g_tn_phase = 2;
-    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid));
+    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T));
     g_tn_phase = 0;
     return 0;
 }
@@ -491,14 +493,22 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s));
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(cb.ssum), m->Wf(cb.ssq), B, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
                           m->P(cb.bn.mm), m->P(cb.bn.mv), r.training, m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.bsh), c, m->s));
-    CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s));
-    CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, m->W(cb.h2), m->Wf(cb.P), m->Wf(cb.Q), nullptr, m->W(cb.h4), B, T, c, m->s));
+    // Drop-path (c5:82-83) on the branch: y = x + rs[b] * (h4 W2 + b2).  Where the fast kernels apply, rs[b] is folded into the per-sample
+    // affine that produces h4 (h4 = rs[b] * (h2 P + Q), free), the GEMM adds rs[b] * b2, and the backward pass needs no scaled copy of
+    // the incoming gradient: dgrad scales its OUTPUT rows, wgrad multiplies h4^T by the plain gradient and weights the bias sum.
     const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
     EpiArgs e2; e2.resid = x;
+    cb.folded = false;
     if (ds.thr) {
         hipLaunchKernelGGL(droppath_kernel, dim3((B + 255) / 256), dim3(256), 0, m->s, m->Wf(cb.rs), B, ds);
         e2.rowscale = m->Wf(cb.rs); e2.T = T;
+        EpiArgs probe = e2; probe.bias = m->P(cb.W2.b);
+        cb.folded = dt == DT_BF16 && !g_force_regstage && gemm_nt_as_applicable(dt, r.M, cb.W2.N, cb.W2.K, cb.W2.ldt, probe) && gemm_nt_as_applicable(dt, r.M, cb.W2.K, cb.W2.N, cb.W2.ldn, probe) &&
+                    gemm_tn_bias_rowscale_ok(dt, dt, dt, r.M, cb.W2.K, cb.W2.N, T);
+        e2.rowscale_bias = cb.folded ? 1 : 0;
     }
+    CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s, cb.folded ? m->Wf(cb.rs) : nullptr));
+    CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, m->W(cb.h2), m->Wf(cb.P), m->Wf(cb.Q), nullptr, m->W(cb.h4), B, T, c, m->s));
     CK(gemm_fwd(m, cb.W2, m->W(cb.h4), dt, m->W(cb.out), dt, r.M, OP_NONE, no, e2));
     return 0;
 }
@@ -622,13 +632,19 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
     OpArgs no;
     const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
     const void* gs = g;                                  // gradient through the drop-path: dY * rs[b]
-    if (ds.thr) {
-        CKP(m, "map_rows", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_ROWSCALE, g, m->W(m->t3), m->Wf(cb.rs), ds, r.M, T, d, m->s));
-        gs = m->W(m->t3);
-    }
     EpiArgs e1;
-    CK(gemm_dgrad(m, cb.W2, gs, dt, m->W(m->t1), r.M, OP_NONE, no, e1));                       // dh4
-    CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
+    if (ds.thr && cb.folded) {                           // h4 carries rs[b] (conv_fwd): dh4 = (g W2^T) * rs[b]; dW2 = h4^T g; db2 = sum_m rs[b(m)] g[m]
+        e1.rowscale = m->Wf(cb.rs); e1.T = T;
+        CK(gemm_dgrad(m, cb.W2, g, dt, m->W(m->t1), r.M, OP_NONE, no, e1));
+        CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, g, dt, OP_NONE, no, r.M, 0, 0, m->Wf(cb.rs), T));
+    } else {
+        if (ds.thr) {
+            CKP(m, "map_rows", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_ROWSCALE, g, m->W(m->t3), m->Wf(cb.rs), ds, r.M, T, d, m->s));
+            gs = m->W(m->t3);
+        }
+        CK(gemm_dgrad(m, cb.W2, gs, dt, m->W(m->t1), r.M, OP_NONE, no, e1));                       // dh4
+        CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
+    }
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
     CKP(m, "eca_bn_bwd_finalize", 0, 0, launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
                                   m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), m->Wf(m->ecap), B, T, c, m->s));

@@ -45,6 +45,7 @@ struct Buf { size_t off = 0; };   // byte offset in the workspace
 struct ConvBlock {
     DenseW W1, W2; int dw = -1, eca = -1; BNp bn; int k = 0; uint32_t site = 0;
     Buf z1, h2, h4, out, ssum, ssq, mean, rstd, a, bsh, gn, sg, P, Q, rs;
+    bool folded = false;      // last training forward folded the drop-path scale into h4 (= rs[b] * (h2 P + Q)): see conv_fwd
 };
 struct FFN {
     Norm ln; float eps; DenseW Wa, Wb; uint32_t site_in = 0, site_out = 0; bool has_out_drop = false;
@@ -182,7 +183,8 @@ void plan_shadow(ishara_model* m, DenseW& w, int min_ldt = 0, int min_ldn = 0);
 // profiled GEMM launches over a planned Dense weight: forward C = epi(A W), dgrad dX = epi(dY W^T), wgrad dW += A^T dY (+ bias grad)
 int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea);
 int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea);
-int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0, int nb_valid = 0);
+int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0, int nb_valid = 0,
+               const float* bias_rowscale = nullptr, int bias_T = 0);
 int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x);
 int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn);
 int r5_ffn_fwd(ishara_model* m, R5FFN& f, const Run& r, const void* x);
