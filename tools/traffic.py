@@ -30,15 +30,20 @@ def load(path, counter):
             a = agg[short(r["Kernel_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
     return agg
 
-fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(fetch) | set(write)):
-    f, nf = fetch.get(k, [0, 0]); w, nw = write.get(k, [0, 0])
-    n = max(nf, nw, 1)
-    out[k] = dict(launches=n, read_bytes_per_launch=2.0 * f * 1024 / n, write_bytes_per_launch=w * 1024 / n,
-                  hbm_bytes_per_launch=(2.0 * f + w) * 1024 / n)
-json.dump(dict(source_hash=source_hash(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline`; "
-                    "KiB units, FETCH_SIZE x2 (gfx950 wide-read correction)", kernels=out), open(sys.argv[3], "w"), indent=1)
-top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]
-for k, v in top:
-    print(f"{k:44s} n={v['launches']:4d} read={v['read_bytes_per_launch']/1e6:8.1f} MB write={v['write_bytes_per_launch']/1e6:8.1f} MB")
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(k, [0, 0]); w, nw = write.get(k, [0, 0])
+        n = max(nf, nw, 1)
+        out[k] = dict(launches=n, read_bytes_per_launch=2.0 * f * 1024 / n, write_bytes_per_launch=w * 1024 / n,
+                      hbm_bytes_per_launch=(2.0 * f + w) * 1024 / n)
+    json.dump(dict(source_hash=source_hash(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py --steps 1 --warmup 0 --no-cpu-baseline`; "
+                        "KiB units, FETCH_SIZE x2 (gfx950 wide-read correction)", kernels=out), open(sys.argv[3], "w"), indent=1)
+    top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]
+    for k, v in top:
+        print(f"{k:44s} n={v['launches']:4d} read={v['read_bytes_per_launch']/1e6:8.1f} MB write={v['write_bytes_per_launch']/1e6:8.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
