@@ -642,6 +642,134 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_win_kernel(const T* __restri
     }
 }
 
+// ---- forward only, 8 channels per lane (16-byte accesses: a wave reads / writes 1 KB of a row per instruction — the 8-byte kernel
+// above tops out near 3.4 TB/s, tools/micro/load_pattern.hip / store_pattern.hip).  K = 3, 5; C % 8 == 0 with C / 8 a divisor of 256.
+// Workgroup = C/8 lanes x (256 / (C/8)) consecutive 32-step segments of one sample; statistics as in dwconv_reg_kernel.
+template <typename T>
+DEVI void dw8_raw(const T* __restrict__ x, int b, int tin, int Tn, int C, int Cin, int ch, int inop, float (&v)[8], float (&g)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = 0.f; g[e] = 0.f; }
+    if (tin < 0 || tin >= Tn) return;
+    const T* p = x + ((size_t)b * Tn + tin) * Cin + ch;
+    load8(p, v);
+    if (inop == DWIN_GLU) load8(p + C, g);
+}
+template <typename T, int K, int INOP>
+__global__ __launch_bounds__(256) void dwconv_reg8_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          T* __restrict__ y, int Tn, int C, int padl, float* __restrict__ part) {
+    constexpr int inop = INOP;
+    extern __shared__ float sred8[];            // [segments per workgroup][C/8][16]
+    const int cg = C >> 3, spw = 256 / cg;
+    const int nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
+    const int cl = threadIdx.x % cg, sl = threadIdx.x / cg;
+    const int seg = blockIdx.x * spw + sl, b = blockIdx.y;
+    const bool live = seg < nseg;
+    const int ch = cl * 8;
+    const int Cin = (inop == DWIN_GLU) ? 2 * C : C;
+    float wr[K][8], win[K][8];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { load4(w + (size_t)j * C + ch, *reinterpret_cast<float(*)[4]>(&wr[j][0])); load4(w + (size_t)j * C + ch + 4, *reinterpret_cast<float(*)[4]>(&wr[j][4])); }
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias) { load4(bias + ch, *reinterpret_cast<float(*)[4]>(&bv[0])); load4(bias + ch + 4, *reinterpret_cast<float(*)[4]>(&bv[4])); }
+    const int t0 = seg * DWR_SEG, tend = live ? min(Tn, t0 + DWR_SEG) : t0;
+    auto xform = [&](float (&v)[8], const float (&g)[8]) {
+        if (inop == DWIN_SWISH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+        } else if (inop == DWIN_GLU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(g[e]);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) { float g8[8]; dw8_raw(x, b, live ? t0 - padl + j : -1, Tn, C, Cin, ch, inop, win[j], g8); xform(win[j], g8); }
+    float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // Two groups of K input rows in flight (ping-pong register sets of RAW 16-byte rows): with one group the kernel is bound by
+    // memory latency x bytes in flight (12 waves per CU x 64 lanes x K x 16 B: 3.7 TB/s by Little's law, as measured)
+    typedef __attribute__((ext_vector_type(4))) uint32_t raw4;
+    struct Grp { raw4 v[K], g[INOP == DWIN_GLU ? K : 1]; };
+    Grp ga, gb;
+    auto issue = [&](Grp& G, int tb) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int tin = tb + u - padl + K - 1;
+            G.v[u] = raw4{0u, 0u, 0u, 0u};
+            if (INOP == DWIN_GLU) G.g[u] = raw4{0u, 0u, 0u, 0u};
+            if (tb + u < tend && tin >= 0 && tin < Tn) {
+                const T* p = x + ((size_t)b * Tn + tin) * Cin + ch;
+                G.v[u] = *reinterpret_cast<const raw4*>(p);
+                if (INOP == DWIN_GLU) G.g[u] = *reinterpret_cast<const raw4*>(p + C);
+            }
+        }
+    };
+    auto unpack = [&](const raw4& r, float (&v)[8]) {
+        T tmp[8];
+        *reinterpret_cast<raw4*>(tmp) = r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = to_f(tmp[e]);
+    };
+    auto process = [&](const Grp& G, int tb) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int t = tb + u;
+            if (t < tend) {
+                float nv[8], ng[8];
+                unpack(G.v[u], nv);
+                if (INOP == DWIN_GLU) unpack(G.g[INOP == DWIN_GLU ? u : 0], ng);
+                xform(nv, ng);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) win[(u + K - 1) % K][e] = nv[e];
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = bv[e];
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += wr[j][e] * win[(u + j) % K][e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1[e] += o[e]; s2[e] += o[e] * o[e]; }
+                store8(y + ((size_t)b * Tn + t) * C + ch, o);
+            }
+        }
+    };
+    issue(ga, t0);
+    for (int tb = t0; tb < tend; tb += 2 * K) {
+        issue(gb, tb + K);
+        process(ga, tb);
+        issue(ga, tb + 2 * K);
+        process(gb, tb + K);
+    }
+    if (part) {     // deterministic partial row of this workgroup's segments: part[B][P = gridDim.x][2][C]
+        float* sr = sred8 + ((size_t)sl * cg + cl) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sr[e] = live ? s1[e] : 0.f; sr[8 + e] = live ? s2[e] : 0.f; }
+        __syncthreads();
+        if (sl == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = 0.f, q = 0.f;
+                for (int r = 0; r < spw; ++r) { a += sred8[((size_t)r * cg + cl) * 16 + e]; q += sred8[((size_t)r * cg + cl) * 16 + 8 + e]; }
+                float* pr = part + (((size_t)b * gridDim.x + blockIdx.x) * 2) * C + ch + e;
+                pr[0] = a; pr[C] = q;
+            }
+        }
+    }
+}
+// applicable: 16-bit storage, K in {3, 5}, C/8 in {32, 64, 128, 256}
+static bool dw_reg8_ok(int dt, int C, int k) { return dt != DT_F32 && (k == 3 || k == 5) && C % 8 == 0 && C / 8 >= 32 && C / 8 <= 256 && 256 % (C / 8) == 0; }
+template <typename T>
+static int launch_dw_reg8(int k, const T* x, const float* w, const float* bias, T* y, int B, int Tn, int C, int padl, int inop, float* part, hipStream_t s) {
+    const int cg = C / 8, spw = 256 / cg, nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
+    const dim3 grid((nseg + spw - 1) / spw, B);
+    const size_t sh = (size_t)256 * 16 * sizeof(float);
+#define DW8(KK, OP) hipLaunchKernelGGL((dwconv_reg8_kernel<T, KK, OP>), grid, dim3(256), sh, s, x, w, bias, y, Tn, C, padl, part)
+#define DW8K(OP) do { if (k == 3) DW8(3, OP); else DW8(5, OP); } while (0)
+    if (inop == DWIN_SWISH) DW8K(DWIN_SWISH); else if (inop == DWIN_GLU) DW8K(DWIN_GLU); else DW8K(DWIN_NONE);
+#undef DW8K
+#undef DW8
+    return (int)grid.x;      // partial rows per sample
+}
+
 static bool dw_reg_ok(int C, int k) { return (k == 3 || k == 5) && C % 4 == 0   /* K = 11, 15: the register window (201 / 233 VGPRs) measured 94 / 103 us vs 82 / 86 us for the LDS-tiled kernel */ && C / 4 <= 256 && 256 % (C / 4) == 0; }
 int g_force_dw_lds = 0;    // tests: force the LDS-tiled kernels
 
@@ -688,7 +816,7 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restri
         else if (k <= 15) hipLaunchKernelGGL((dwconv_kernel<TT, 0, 15>), grid, dim3(256), 0, s, __VA_ARGS__);   /* K = 15 unrolled: 86 vs 78 us */ \
         else hipLaunchKernelGGL((dwconv_kernel<TT, 0, DW_MAXK>), grid, dim3(256), 0, s, __VA_ARGS__);            \
     } while (0)
-size_t dwconv_fwd_scratch_floats(int B, int T, int C) { return (size_t)B * ((T + DW_TT - 1) / DW_TT) * 2 * C; }
+size_t dwconv_fwd_scratch_floats(int B, int T, int C) { return (size_t)B * ((T + DWR_SEG - 1) / DWR_SEG) * 2 * C; }   // the most partial rows any forward kernel writes per sample (one per 32-step segment)
 
 // `part`: scratch of dwconv_fwd_scratch_floats(B, T, C) floats for the deterministic statistics, or nullptr (then colsum /
 // colsq must be zero-filled by the caller and are accumulated with float atomics)
@@ -697,7 +825,10 @@ int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const flo
     if (dwconv_check(C, k)) return -1;
     if (!colsum) part = nullptr;
     int P;
-    if (dw_reg_ok(C, k) && !g_force_dw_lds) {
+    if (dw_reg8_ok(dt, C, k) && !g_force_dw_lds && (part || !colsum)) {          // statistics only through the deterministic partial rows
+        if (dt == DT_BF16) P = launch_dw_reg8<bf16>(k, (const bf16*)x, w, bias, (bf16*)y, B, T, C, padl, inop, colsum ? part : nullptr, s);
+        else P = launch_dw_reg8<f16>(k, (const f16*)x, w, bias, (f16*)y, B, T, C, padl, inop, colsum ? part : nullptr, s);
+    } else if (dw_reg_ok(C, k) && !g_force_dw_lds) {
         const int nseg = (T + DWR_SEG - 1) / DWR_SEG;
         P = (nseg + 3) / 4;
         if (dt == DT_BF16) launch_dw_reg<bf16>(k, (const bf16*)x, w, bias, (bf16*)y, (const bf16*)nullptr, colsum, colsq, B, T, C, padl, inop, OUT_NONE, 0, s, part);
