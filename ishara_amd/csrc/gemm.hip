@@ -968,6 +968,9 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
         if (dtA == DT_F16 && dtC == DT_F32) return run_nt<f16, f16, float, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
         ishara_set_error("gemm_nt: unsupported f16 dtype combination %d/%d/%d", dtA, dtM, dtC); return -1;
     }
+    if ((ea.ln_gamma || ea.pa_P) && (op != OP_NONE || !gemm_nt_as_prologue_ok(dtA, dtM, dtC, M, N, K, ldb, ea))) {
+        ishara_set_error("gemm_nt: operand prologue requested for a shape the A-stationary kernel does not take (check gemm_nt_as_prologue_ok first)"); return -1;
+    }
     const int bk = dtM == DT_BF16 ? 32 : 16;     // K tile of the LDS-DMA kernel
     const bool dma_ok = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0;
     if (dma_ok && g_force_regstage == 0 && dtM == DT_BF16) {

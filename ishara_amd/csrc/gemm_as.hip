@@ -28,6 +28,9 @@
 #include "common.h"
 #include "kernels.h"
 
+extern int g_force_regstage;
+bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
+
 #define AS_NS 32            // output columns (staged weight rows) per step
 #define AS_MAXN 1024
 
@@ -64,7 +67,9 @@ template <int MASK, int F> DEVI bool as_on(bool runtime) {
 
 // One pass of a workgroup over all N columns for the rows [m_base, m_base + 64*RT): wave w owns rows m_base + 16*RT*w ..,
 // RT row tiles of 16.  KT = K / 32 (8 or 16); MASK: epilogue features.
-template <typename TC, int KT, int MASK, int RT, int DBG>
+// PRO: operand prologue — 0 none, 1 LayerNorm over K (ea.ln_*), 2 per-sample affine (ea.pa_*); both write the transformed rows to
+// ea.pro_out when it is set.  The coefficient vectors are staged in the ring slot the DMA fills last (free until step 0's issue).
+template <typename TC, int KT, int MASK, int RT, int DBG, int PRO>
 DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, const EpiArgs& ea,
                   char* smem, const float* bias_s, int m_base) {
     constexpr int RB = KT * 64;                    // bytes of one staged weight row (full K)
@@ -127,6 +132,85 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
         const bf16x8* p = reinterpret_cast<const bf16x8*>(A + (size_t)mrow[i] * K + g * 8);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) a[i][kt] = p[kt * 4];
+    }
+
+    if constexpr (PRO != 0) {
+        float* cs = reinterpret_cast<float*>(smem + (R - 1) * STAGE);       // [2][K] coefficients: gamma | beta   or   P[b] | Q[b]
+        const int bsm = min(m_base, M - 1) / ea.T;                          // PRO 2: the workgroup's rows lie in ONE sample (launcher)
+        const float* c0 = PRO == 1 ? ea.ln_gamma : ea.pa_P + (size_t)bsm * K;
+        const float* c1 = PRO == 1 ? ea.ln_beta : ea.pa_Q + (size_t)bsm * K;
+        for (int x = tid; x < K; x += 256) { cs[x] = c0[x]; cs[K + x] = c1[x]; }
+        __syncthreads();
+        // Every pass over the fragments unpacks them again from the packed registers, behind an opaque asm: otherwise hipcc keeps
+        // all 8*KT*RT unpacked floats alive across the three passes (statistics, variance, normalise) and spills hundreds of VGPRs.
+        auto unpack = [&](const bf16x8& f, float (&v)[8]) {
+            as_u32x4 t = __builtin_bit_cast(as_u32x4, f);
+            asm volatile("" : "+v"(t));
+            as_unpack<bf16, 8>(t, v);
+        };
+        float mean[RT], rstd[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) { mean[i] = 0.f; rstd[i] = 1.f; }
+        if constexpr (PRO == 1) {              // exact two-pass statistics over the lane's 8*KT values, then over the row's 4 lanes
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    float v[8];
+                    unpack(a[i][kt], v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s += v[e];
+                }
+                s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                mean[i] = s * (1.f / K);
+                float q = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    float v[8];
+                    unpack(a[i][kt], v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float dlt = v[e] - mean[i]; q += dlt * dlt; }
+                }
+                q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+                rstd[i] = rsqrtf(q * (1.f / K) + ea.ln_eps);
+                const int m = mw + 16 * i + c;
+                if (g == 0 && m < M && ea.ln_mean) { ea.ln_mean[m] = mean[i]; ea.ln_rstd[m] = rstd[i]; }
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {      // coefficients of this k slice live for the RT row tiles only
+            float wv[8], bv[8];
+            {
+                const float* cp = cs + 32 * kt + 8 * g;
+                asm volatile("" : "+v"(cp));
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(cp), w1 = *reinterpret_cast<const f32x4*>(cp + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(cp + K), b1 = *reinterpret_cast<const f32x4*>(cp + K + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { wv[e] = w0[e]; wv[4 + e] = w1[e]; bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+            }
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                float v[8];
+                unpack(a[i][kt], v);
+                bf16x8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (bf16)(PRO == 1 ? (v[e] - mean[i]) * rstd[i] * wv[e] + bv[e] : v[e] * wv[e] + bv[e]);
+                a[i][kt] = t;
+            }
+        }
+        if (ea.pro_out) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int m = mw + 16 * i + c;
+                if (m < M) {
+                    bf16x8* p = reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(ea.pro_out) + (size_t)m * K + g * 8);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) p[kt * 4] = a[i][kt];
+                }
+            }
+        }
+        __syncthreads();                     // the coefficient slot is free again before any wave reaches step 0's DMA issue
     }
 
     // weight fragment reads: MFMA tile j, tile row t = c comes from staged row
@@ -333,7 +417,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 // K = 256: 128-row workgroups, 3 per CU (768 at M = 98304 = one round of the chip).  K = 512: the A fragments take 128
 // VGPRs, so only 2 workgroups fit per CU; 192-row workgroups (512 at M = 98304, again exactly one round) run as a
 // 128-row pass followed by a 64-row pass.
-template <typename TC, int KT, int MASK, int DBG = 0>
+template <typename TC, int KT, int MASK, int DBG = 0, int PRO = 0>
 __global__ __launch_bounds__(256, KT <= 8 ? 3 : 2) void gemm_nt_as_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C,
                                                                          int M, int N, int ldb, EpiArgs ea) {
     constexpr int R = KT <= 8 ? 3 : 2;
@@ -343,13 +427,13 @@ __global__ __launch_bounds__(256, KT <= 8 ? 3 : 2) void gemm_nt_as_kernel(const 
     // bias -> LDS (visible after the first barrier of the step loop)
     for (int n = threadIdx.x; n < N; n += 256) bias_s[n] = ea.bias ? ea.bias[n] : 0.f;
     if constexpr (KT <= 8) {
-        as_pass<TC, KT, MASK, 2, DBG>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
+        as_pass<TC, KT, MASK, 2, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
     } else {
         const int m_base = blockIdx.x * 192;
-        as_pass<TC, KT, MASK, 2, DBG>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base);
+        as_pass<TC, KT, MASK, 2, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base);
         if (m_base + 128 < M) {
             __builtin_amdgcn_s_barrier();          // every wave is done reading the ring before the second pass refills it
-            as_pass<TC, KT, MASK, 1, DBG>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base + 128);
+            as_pass<TC, KT, MASK, 1, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base + 128);
         }
     }
 }
@@ -381,6 +465,30 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     while (gy < 4 && gx * gy * 2 <= slots && (N / AS_NS) % (gy * 2) == 0 && N / (gy * 2) >= 128) gy *= 2;
     const dim3 grid(gx, gy), block(256);
     const int mask = as_mask_of(ea);
+    if constexpr (is_bf16_t<TC>::value && KT >= 8) {
+#define AS_PRO(MASK, PRO) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK, 0, PRO>), grid, block, 0, s, (const bf16*)A, (const bf16*)Bt, (TC*)C, M, N, ldb, ea)
+        if (ea.ln_gamma) {           // LayerNorm prologue: the GEMMs that consume a LayerNorm output (FFN expand, QKV, conv-module expand)
+            if (gy != 1) { ishara_set_error("gemm_nt_as: prologue with split columns"); return -1; }
+            switch (mask) {
+                case 0: AS_PRO(0, 1); break;
+                case AS_ACT | AS_PREOUT: AS_PRO(AS_ACT | AS_PREOUT, 1); break;
+                case AS_ACT | AS_PREOUT | AS_DROP: AS_PRO(AS_ACT | AS_PREOUT | AS_DROP, 1); break;
+                case AS_QKV: AS_PRO(AS_QKV, 1); break;
+                default: ishara_set_error("gemm_nt_as: LayerNorm prologue with epilogue mask %d is not compiled", mask); return -1;
+            }
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
+        if (ea.pa_P) {               // per-sample affine prologue: the project GEMM of a Conv1DBlock
+            if (gy != 1) { ishara_set_error("gemm_nt_as: prologue with split columns"); return -1; }
+            switch (mask) {
+                case AS_RESID: AS_PRO(AS_RESID, 2); break;
+                case AS_RESID | AS_ROWSCALE: AS_PRO(AS_RESID | AS_ROWSCALE, 2); break;
+                default: ishara_set_error("gemm_nt_as: affine prologue with epilogue mask %d is not compiled", mask); return -1;
+            }
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
+#undef AS_PRO
+    }
     if constexpr (KT == 4) {
         if (mask == AS_DACT) AS_LAUNCH(AS_DACT); else if (mask == (AS_DACT | AS_DROP)) AS_LAUNCH(AS_DACT | AS_DROP); else AS_LAUNCH(AS_ALL);
     } else if constexpr (is_bf16_t<TC>::value) {
@@ -411,6 +519,17 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
 }
 #undef AS_LAUNCH
 
+bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
+    if (dtA != DT_BF16 || dtM != DT_BF16 || dtC != DT_BF16 || (K != 256 && K != 512) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
+    if (ldb % 64 != 0 || g_force_regstage) return false;
+    const int BR = K == 256 ? 128 : 192, gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : 512;
+    if (gx * 2 <= slots && (N / AS_NS) % 2 == 0 && N / 2 >= 128) return false;      // the launcher would split the columns: every split would redo (and rewrite) the prologue
+    const int mask = as_mask_of(ea);
+    if (ea.ln_gamma) return mask == 0 || mask == (AS_ACT | AS_PREOUT) || mask == (AS_ACT | AS_PREOUT | AS_DROP) || mask == AS_QKV;
+    if (ea.pa_P) return ea.T > 0 && ea.T % BR == 0 && (mask == AS_RESID || mask == (AS_RESID | AS_ROWSCALE));   // a workgroup's rows inside one sample
+    return false;
+}
+
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
     if (K != 256 && K != 512 && !(K == 128 && dtC == DT_BF16)) return false;
     if (N % AS_NS != 0 || N > AS_MAXN || ldb < K || ldb % 8 != 0 || M < 1) return false;
@@ -422,11 +541,13 @@ bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs&
 const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea) {
     static std::map<int, std::string> names;
     const int inst = as_inst_mask(dtC == DT_BF16, as_mask_of(ea), K);
-    const int id = (dtC == DT_BF16 ? 0 : 1 << 20) | (K << 8) | inst;
+    const int pro = ea.ln_gamma ? 1 : (ea.pa_P ? 2 : 0);
+    const int id = (dtC == DT_BF16 ? 0 : 1 << 20) | (pro << 22) | (K << 8) | inst;
     auto it = names.find(id);
     if (it == names.end()) {
         char buf[96];
-        snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d,0>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, inst);
+        if (pro) snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d,0,%d>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, as_mask_of(ea), pro);
+        else snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d,0>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, inst);
         it = names.emplace(id, buf).first;
     }
     return it->second.c_str();

@@ -38,6 +38,16 @@ struct EpiArgs {
     void* q = nullptr; void* k = nullptr; void* vt = nullptr;
     int H = 1, dh = 1;
     int dbg = 0;                      // ablation bits (tools/gemm_ablate.py): 1 skip epilogue, 2 skip MFMA, 4 skip loads
+    // ---- prologues of the A-stationary kernel (gemm_as.hip): the operand rows are transformed in registers after the load, and the
+    // transformed rows are written out once (the weight-gradient GEMM of the backward pass needs them in memory)
+    const float* ln_gamma = nullptr;  // LayerNorm over K (the wave holds whole rows): A' = (A - mean) * rstd * gamma + beta
+    const float* ln_beta = nullptr;
+    float ln_eps = 0.f;
+    float* ln_mean = nullptr;         // [M] row statistics for the LayerNorm backward (may be null)
+    float* ln_rstd = nullptr;
+    const float* pa_P = nullptr;      // per-sample affine: A' = A * pa_P[m / T, k] + pa_Q[m / T, k]   (BatchNorm + ECA gate of a Conv1DBlock)
+    const float* pa_Q = nullptr;
+    void* pro_out = nullptr;          // A' rows [M, K] in the operand type (null: not needed, inference)
     int head_major = 1;               // 1: cols = h*3dh + {q,k,v}*dh + i (TF path); 0: {q,k,v}*d + h*dh + i (torch twin)
 };
 
@@ -58,7 +68,9 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
 // xb[M, Kp] (bf16) = x[M, F] (f32), zero padded to Kp columns (F % 4 == 0, Kp % 8 == 0)
 int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s);
 
-bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);   // gemm_as.hip: the A-stationary kernel takes this shape
+bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
+// the kernel also takes ea's prologue (ln_* / pa_*): bf16 output, K in {256, 512}, whole 16-row tiles inside one sample for pa_*
+bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);   // gemm_as.hip: the A-stationary kernel takes this shape
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
 extern int g_force_tn_regstage;   // tests: 1 forces the register-transposing TN kernel
 extern int g_tn_phase;   // 0 GEMM + slab sums, 1 GEMM kernel only, 2 slab sums only

@@ -485,6 +485,27 @@ int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop
 }
 
 
+// LayerNorm as a prologue of the GEMM that consumes it (gemm_as.hip): the wave holds whole rows of K, so the statistics cost two
+// cross-lane adds; the normalised rows go to `xn` (training: the weight-gradient GEMM reads them) and the statistics to mean / rstd.
+// Shapes the A-stationary kernel does not take run the separate LayerNorm kernel.  Returns the GEMM's A operand.
+static const void* ln_prologue(ishara_model* m, const DenseW& w, const Run& r, const void* x, const Norm& ln, float eps, Buf xn, Buf mean, Buf rstd, EpiArgs& ea, int* rc) {
+    *rc = 0;
+    EpiArgs probe = ea;
+    probe.ln_gamma = m->P(ln.gamma); probe.ln_beta = m->P(ln.beta);
+    if (gemm_nt_as_prologue_ok(m->dt, m->dt, m->dt, r.M, w.N, w.K, w.ldt, probe)) {
+        ea.ln_gamma = m->P(ln.gamma); ea.ln_beta = m->P(ln.beta); ea.ln_eps = eps;
+        ea.ln_mean = m->Wf(mean); ea.ln_rstd = m->Wf(rstd);
+        ea.pro_out = r.training ? m->W(xn) : nullptr;
+        return x;
+    }
+    ProfRec* _pr = nullptr; (void)_pr;
+    *rc = [&]() -> int {
+        CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(m->dt, x, m->P(ln.gamma), m->P(ln.beta), eps, m->W(xn), m->Wf(mean), m->Wf(rstd), r.M, m->d, m->s));
+        return 0;
+    }();
+    return m->W(xn);
+}
+
 // ------------------------------------------------------------------ module forward
 static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x) {
     const int d = m->d, c = 2 * d, B = r.B, T = m->T, dt = m->dt;
@@ -508,6 +529,16 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
         e2.rowscale_bias = cb.folded ? 1 : 0;
     }
     CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s, cb.folded ? m->Wf(cb.rs) : nullptr));
+    // h4 = h2 * P[b] + Q[b] (BatchNorm + ECA gate [+ drop-path]) as a prologue of the project GEMM: h2 is read once, h4 is written from
+    // the transformed fragments for the weight-gradient GEMM (training only); other shapes run the separate affine pass
+    {
+        EpiArgs probe = e2; probe.pa_P = m->Wf(cb.P); probe.pa_Q = m->Wf(cb.Q); probe.T = T; probe.bias = m->P(cb.W2.b);
+        if (gemm_nt_as_prologue_ok(dt, dt, dt, r.M, cb.W2.N, cb.W2.K, cb.W2.ldt, probe)) {
+            e2.pa_P = m->Wf(cb.P); e2.pa_Q = m->Wf(cb.Q); e2.T = T; e2.pro_out = r.training ? m->W(cb.h4) : nullptr;
+            CK(gemm_fwd(m, cb.W2, m->W(cb.h2), dt, m->W(cb.out), dt, r.M, OP_NONE, no, e2));
+            return 0;
+        }
+    }
     CKP(m, "sample_affine", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_affine(dt, m->W(cb.h2), m->Wf(cb.P), m->Wf(cb.Q), nullptr, m->W(cb.h4), B, T, c, m->s));
     CK(gemm_fwd(m, cb.W2, m->W(cb.h4), dt, m->W(cb.out), dt, r.M, OP_NONE, no, e2));
     return 0;
@@ -516,9 +547,11 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
 static int ffn_fwd(ishara_model* m, FFN& f, const Run& r, const void* x) {
     const int dt = m->dt;
     OpArgs no;
-    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, x, m->P(f.ln.gamma), m->P(f.ln.beta), f.eps, m->W(f.xn), m->Wf(f.mean), m->Wf(f.rstd), r.M, m->d, m->s));
     EpiArgs ea; ea.pre_out = m->W(f.za); ea.act = ACT_SWISH; ea.drop = dspec(r, f.site_in, m->cfg.dropout_rate);
-    CK(gemm_fwd(m, f.Wa, m->W(f.xn), dt, m->W(f.u), dt, r.M, OP_NONE, no, ea));
+    int rc;
+    const void* ain = ln_prologue(m, f.Wa, r, x, f.ln, f.eps, f.xn, f.mean, f.rstd, ea, &rc);
+    CK(rc);
+    CK(gemm_fwd(m, f.Wa, ain, dt, m->W(f.u), dt, r.M, OP_NONE, no, ea));
     EpiArgs eb; eb.resid = x;
     if (f.has_out_drop) eb.drop = dspec(r, f.site_out, m->cfg.dropout_rate);
     CK(gemm_fwd(m, f.Wb, m->W(f.u), dt, m->W(f.out), dt, r.M, OP_NONE, no, eb));
@@ -528,9 +561,11 @@ static int ffn_fwd(ishara_model* m, FFN& f, const Run& r, const void* x) {
 static int mhsa_fwd(ishara_model* m, MHSA& a, const Run& r, const void* x) {
     const int dt = m->dt;
     OpArgs no;
-    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, x, m->P(a.ln.gamma), m->P(a.ln.beta), a.eps, m->W(a.xn), m->Wf(a.mean), m->Wf(a.rstd), r.M, m->d, m->s));
     EpiArgs eq; eq.mode = EPI_QKV; eq.q = m->W(a.q); eq.k = m->W(a.k); eq.vt = m->W(a.vt); eq.H = m->H; eq.dh = m->dh; eq.T = m->T; eq.head_major = 1;
-    CK(gemm_fwd(m, a.Wqkv, m->W(a.xn), dt, nullptr, dt, r.M, OP_NONE, no, eq));
+    int rc;
+    const void* ain = ln_prologue(m, a.Wqkv, r, x, a.ln, a.eps, a.xn, a.mean, a.rstd, eq, &rc);
+    CK(rc);
+    CK(gemm_fwd(m, a.Wqkv, ain, dt, nullptr, dt, r.M, OP_NONE, no, eq));
     const float scale = 1.0f / sqrtf((float)m->d);     // self.scale = dim ** -0.5 (c5:95)
     CKP(m, "attn_fwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 4.0 * r.B * m->H * (double)m->T * m->T * m->dh, launch_attn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->Wf(a.lse), r.B, m->H, m->T, m->dh, scale,
                        dspec(r, a.site_attn, a.rate), m->cfg.attn_impl, reinterpret_cast<uint32_t*>(m->W(a.maskw)), m->s));
@@ -543,8 +578,11 @@ static int mhsa_fwd(ishara_model* m, MHSA& a, const Run& r, const void* x) {
 static int sqzconv_fwd(ishara_model* m, SqzConv& c, const Run& r, const void* x) {
     const int dt = m->dt, d = m->d, de = c.Wc1.N, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
-    CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(dt, x, m->P(c.ln.gamma), m->P(c.ln.beta), 1e-6f, m->W(c.xn), m->Wf(c.mean), m->Wf(c.rstd), r.M, d, m->s));
-    CK(gemm_fwd(m, c.Wc1, m->W(c.xn), dt, m->W(c.zc), dt, r.M, OP_NONE, no, e0));
+    EpiArgs e1;
+    int rc;
+    const void* ain = ln_prologue(m, c.Wc1, r, x, c.ln, 1e-6f, c.xn, c.mean, c.rstd, e1, &rc);
+    CK(rc);
+    CK(gemm_fwd(m, c.Wc1, ain, dt, m->W(c.zc), dt, r.M, OP_NONE, no, e1));
     CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(c.zc), m->P(c.dw), nullptr, m->W(c.zd), nullptr, nullptr, nullptr, B, T, de, c.k, c.k - 1, m->s));
     CKP(m, "map_rows", 2.0 * r.M * de * (double)dt_size(m->dt), 0, launch_map_rows(dt, MAP_SWISH, m->W(c.zd), m->W(c.hd), nullptr, DropSpec{0, 0, 1.f}, r.M, T, de, m->s));
     CK(gemm_fwd(m, c.Wc3, m->W(c.hd), dt, m->W(c.u3), dt, r.M, OP_NONE, no, e0));
