@@ -69,7 +69,7 @@ template <int MASK, int F> DEVI bool as_on(bool runtime) {
 // RT row tiles of 16.  KT = K / 32 (8 or 16); MASK: epilogue features.
 // PRO: operand prologue — 0 none, 1 LayerNorm over K (ea.ln_*), 2 per-sample affine (ea.pa_*); both write the transformed rows to
 // ea.pro_out when it is set.  The coefficient vectors are staged in the ring slot the DMA fills last (free until step 0's issue).
-template <typename TC, int KT, int MASK, int RT, int DBG, int PRO>
+template <typename TC, int KT, int MASK, int RT, int DBG, int PRO, int NW = 4>
 DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, const EpiArgs& ea,
                   char* smem, const float* bias_s, int m_base) {
     constexpr int RB = KT * 64;                    // bytes of one staged weight row (full K)
@@ -77,7 +77,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
     constexpr int STAGE = NS * RB;                 // 16 KB (K=256) / 32 KB (K=512)
     constexpr int R = KT <= 8 ? 3 : 2;             // ring depth: 48 KB / 64 KB of LDS
     constexpr int K = KT * 32;
-    constexpr int DPW = STAGE / 1024 / 4;          // 1 KB DMA instructions per wave per stage
+    constexpr int DPW = STAGE / 1024 / NW;         // 1 KB DMA instructions per wave per stage (NW waves per workgroup)
     constexpr bool PAIR = is_bf16_t<TC>::value;    // pair MFMA tiles so that a lane owns 8 consecutive columns (16-byte bf16 accesses)
     constexpr int GW = PAIR ? 8 : 4;               // columns per lane per group
     constexpr int NG = NS / (4 * GW);              // groups per row tile per step: 1 (bf16 C) / 2 (f32 C)
@@ -90,7 +90,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int mw = m_base + wid * 16 * RT;                   // first row of this wave
-    const bool full = m_base + 64 * RT <= M;
+    const bool full = m_base + NW * 16 * RT <= M;
     // blockIdx.y splits the N columns between workgroups when M alone gives too few of them (launcher): this one covers
     // the column steps [nbase / NS, nbase / NS + nsteps)
     const int nsteps = N / NS / (int)gridDim.y;
@@ -139,7 +139,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
         const int bsm = min(m_base, M - 1) / ea.T;                          // PRO 2: the workgroup's rows lie in ONE sample (launcher)
         const float* c0 = PRO == 1 ? ea.ln_gamma : ea.pa_P + (size_t)bsm * K;
         const float* c1 = PRO == 1 ? ea.ln_beta : ea.pa_Q + (size_t)bsm * K;
-        for (int x = tid; x < K; x += 256) { cs[x] = c0[x]; cs[K + x] = c1[x]; }
+        for (int x = tid; x < K; x += NW * 64) { cs[x] = c0[x]; cs[K + x] = c1[x]; }
         __syncthreads();
         // Every pass over the fragments unpacks them again from the packed registers, behind an opaque asm: otherwise hipcc keeps
         // all 8*KT*RT unpacked floats alive across the three passes (statistics, variance, normalise) and spills hundreds of VGPRs.
@@ -418,16 +418,21 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 // VGPRs, so only 2 workgroups fit per CU; 192-row workgroups (512 at M = 98304, again exactly one round) run as a
 // 128-row pass followed by a 64-row pass.
 template <typename TC, int KT, int MASK, int DBG = 0, int PRO = 0>
-__global__ __launch_bounds__(256, KT <= 8 ? 3 : 2) void gemm_nt_as_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C,
+__global__ __launch_bounds__(KT <= 16 ? 256 : 512, KT <= 8 ? 3 : (KT <= 16 ? 2 : 1)) void gemm_nt_as_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C,
                                                                          int M, int N, int ldb, EpiArgs ea) {
     constexpr int R = KT <= 8 ? 3 : 2;
     constexpr int STAGE = AS_NS * KT * 64;
     __shared__ __attribute__((aligned(16))) char smem[R * STAGE + AS_MAXN * 4];
     float* bias_s = reinterpret_cast<float*>(smem + R * STAGE);
     // bias -> LDS (visible after the first barrier of the step loop)
-    for (int n = threadIdx.x; n < N; n += 256) bias_s[n] = ea.bias ? ea.bias[n] : 0.f;
+    for (int n = threadIdx.x; n < N; n += (int)blockDim.x) bias_s[n] = ea.bias ? ea.bias[n] : 0.f;
     if constexpr (KT <= 8) {
         as_pass<TC, KT, MASK, 2, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
+    } else if constexpr (KT >= 32) {
+        // K = 1024 (config #4's 2d = 1024 operands): 16 rows per wave (the fragments of ONE row tile already take 128 VGPRs), EIGHT
+        // waves = 128-row workgroups around a ring of 2 x 64 KB -> one workgroup per CU, two waves per SIMD.  Half the rows per staged
+        // weight byte of the K <= 512 variants, so the LDS fragment reads bound it near half the MFMA peak.
+        as_pass<TC, KT, MASK, 1, DBG, PRO, 8>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
     } else {
         const int m_base = blockIdx.x * 192;
         as_pass<TC, KT, MASK, 2, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, m_base);
@@ -457,13 +462,13 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
 #define AS_LAUNCH(MASK) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK>), grid, block, 0, s, (const bf16*)A, (const bf16*)Bt, (TC*)C, M, N, ldb, ea)
 template <typename TC, int KT>
 static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea, hipStream_t s) {
-    constexpr int BR = KT <= 8 ? 128 : 192;      // rows per workgroup
+    constexpr int BR = KT <= 8 ? 128 : (KT <= 16 ? 192 : 128);     // rows per workgroup
     // few rows (config #4 at small batches: M / 192 = 171 workgroups for 512 slots): split the columns 2- or 4-way; every
     // workgroup then loads its A rows again, which is cheap exactly when M is small
-    const int gx = (M + BR - 1) / BR, slots = KT <= 8 ? 768 : 512;
+    const int gx = (M + BR - 1) / BR, slots = KT <= 8 ? 768 : (KT <= 16 ? 512 : 256);
     int gy = 1;
     while (gy < 4 && gx * gy * 2 <= slots && (N / AS_NS) % (gy * 2) == 0 && N / (gy * 2) >= 128) gy *= 2;
-    const dim3 grid(gx, gy), block(256);
+    const dim3 grid(gx, gy), block(KT <= 16 ? 256 : 512);
     const int mask = as_mask_of(ea);
     if constexpr (is_bf16_t<TC>::value && KT >= 8) {
 #define AS_PRO(MASK, PRO) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK, 0, PRO>), grid, block, 0, s, (const bf16*)A, (const bf16*)Bt, (TC*)C, M, N, ldb, ea)
@@ -520,9 +525,9 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
 #undef AS_LAUNCH
 
 bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
-    if (dtA != DT_BF16 || dtM != DT_BF16 || dtC != DT_BF16 || (K != 256 && K != 512) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
+    if (dtA != DT_BF16 || dtM != DT_BF16 || dtC != DT_BF16 || (K != 256 && K != 512 && K != 1024) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
     if (ldb % 64 != 0 || g_force_regstage) return false;
-    const int BR = K == 256 ? 128 : 192, gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : 512;
+    const int BR = K == 256 ? 128 : (K == 512 ? 192 : 128), gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : (K == 512 ? 512 : 256);
     if (gx * 2 <= slots && (N / AS_NS) % 2 == 0 && N / 2 >= 128) return false;      // the launcher would split the columns: every split would redo (and rewrite) the prologue
     const int mask = as_mask_of(ea);
     if (ea.ln_gamma) return mask == 0 || mask == (AS_ACT | AS_PREOUT) || mask == (AS_ACT | AS_PREOUT | AS_DROP) || mask == AS_QKV;
@@ -531,7 +536,7 @@ bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int 
 }
 
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
-    if (K != 256 && K != 512 && !(K == 128 && dtC == DT_BF16)) return false;
+    if (K != 256 && K != 512 && !((K == 128 || K == 1024) && dtC == DT_BF16)) return false;
     if (N % AS_NS != 0 || N > AS_MAXN || ldb < K || ldb % 8 != 0 || M < 1) return false;
     if (ea.mode == EPI_QKV && (ea.dh % 8 != 0 || ea.T % 8 != 0)) return false;
     return true;
@@ -556,6 +561,7 @@ const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea) {
 // returns 1 when the shape is not one this kernel takes (caller falls through to the tile kernels)
 int launch_gemm_nt_as(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s) {
     if (!gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return 1;
-    if (dtC == DT_BF16) return K == 128 ? run_as<bf16, 4>(A, Bt, C, M, N, ldb, ea, s) : (K == 256 ? run_as<bf16, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<bf16, 16>(A, Bt, C, M, N, ldb, ea, s));
+    if (dtC == DT_BF16) return K == 128 ? run_as<bf16, 4>(A, Bt, C, M, N, ldb, ea, s) : (K == 256 ? run_as<bf16, 8>(A, Bt, C, M, N, ldb, ea, s) :
+                               (K == 512 ? run_as<bf16, 16>(A, Bt, C, M, N, ldb, ea, s) : run_as<bf16, 32>(A, Bt, C, M, N, ldb, ea, s)));
     return K == 256 ? run_as<float, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<float, 16>(A, Bt, C, M, N, ldb, ea, s);
 }
