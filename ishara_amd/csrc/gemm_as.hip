@@ -46,6 +46,16 @@ DEVI int as_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 template <int GW, typename T> DEVI void as_st(T* p, const float (&v)[GW]) {
     if constexpr (GW == 8) store8(p, v); else store4(p, v);
 }
+// the same with the non-temporal hint: tensors that are only read again in the BACKWARD pass (saved pre-activations, the prologues'
+// transformed rows) should not push the tensors the next launch reads out of L2 / Infinity Cache
+template <int GW, typename T> DEVI void as_st_nt(T* p, const float (&v)[GW]) {
+    if constexpr (GW == 8 && is_bf16_t<T>::value) {
+        bf16x8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+        __builtin_nontemporal_store(t, reinterpret_cast<bf16x8*>(p));
+    } else as_st<GW>(p, v);
+}
 // 16 bytes of TC -> GW floats (8 bf16 / 4 f32)
 template <typename TC, int GW> DEVI void as_unpack(const as_u32x4& r, float (&v)[GW]) {
     if constexpr (GW == 8) {
@@ -206,7 +216,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
                 if (m < M) {
                     bf16x8* p = reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(ea.pro_out) + (size_t)m * K + g * 8);
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) p[kt * 4] = a[i][kt];
+                    for (int kt = 0; kt < KT; ++kt) __builtin_nontemporal_store(a[i][kt], &p[kt * 4]);
                 }
             }
         }
@@ -359,7 +369,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
                         for (int e = 0; e < 4; ++e) v[4 * h + e] += t4[e];
                     }
                 }
-                if (f_preout) as_st<GW>(reinterpret_cast<TC*>(ea.pre_out) + off, v);
+                if (f_preout) as_st_nt<GW>(reinterpret_cast<TC*>(ea.pre_out) + off, v);
                 if (f_act) {
                     if (ea.act == ACT_SWISH) {
 #pragma unroll
