@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
                 pb[t][ks] = __builtin_bit_cast(bf16x8, w);
             }
         }
-        if constexpr (DM == 2) maskbits[((size_t)(bh * nqb + xb) * nch + ch) * 256 + tid] = keepbits;
+        if constexpr (DM == 2) __builtin_nontemporal_store(keepbits, &maskbits[((size_t)(bh * nqb + xb) * nch + ch) * 256 + tid]);      // read again only by the backward pass
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dq_mfma_kernel
         const bf16* Vc = Vs[ch & 1];
         const int key0 = ch * AF_KC;
         const bool partial = key0 + AF_KC > Tn;      // only the last chunk needs per-key bounds masks
-        const uint32_t keepbits = DM == 2 ? maskbits[((size_t)(bh * nqb + xb) * nch + ch) * 256 + tid] : 0u;
+        const uint32_t keepbits = DM == 2 ? __builtin_nontemporal_load(&maskbits[((size_t)(bh * nqb + xb) * nch + ch) * 256 + tid]) : 0u;
         bf16x8 dsb[2][2];
         {
             f32x4 sacc[4][2], dpa[4][2];

@@ -25,7 +25,7 @@ template <typename T> struct DwRow;
 template <> struct DwRow<bf16> {
     dwu2 r;
     DEVI void zero() { r = dwu2{0u, 0u}; }
-    DEVI void load(const bf16* p) { r = *reinterpret_cast<const dwu2*>(p); }
+    DEVI void load(const bf16* p) { r = __builtin_nontemporal_load(reinterpret_cast<const dwu2*>(p)); }      // every operand of the backward conv is at its last use
     DEVI void unpack(dwf2& lo, dwf2& hi) const {
         lo = dwf2{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
         hi = dwf2{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};

@@ -1165,6 +1165,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define TR_STAGE 16384          // A 32 rows x 256 B + B 32 rows x 256 B
 #define TR_ROWS 32
+#define TR_AUX 0             // cache policy of the operand DMA: 0 = default: the tiles of one M-split share the operand rows through L2 (non-temporal, 2, measured 2.38 -> 2.87 ms/step of wgrad)
 #define TR_NSTAGE 4          // measured: 3 stages (3 workgroups/CU) 116 us, 4 stages (2/CU) 90 us, 5 stages (80 KB, 1-2/CU) 94 us per wgrad
 
 DEVI int tr_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -1307,9 +1308,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                  \
             const int pc = wid + 4 * u;                                                                                  \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa[u],                       \
-                                             (__attribute__((address_space(3))) void*)(smem + (SLOT) * TR_STAGE + pc * 1024), 16, 0, 0);        \
+                                             (__attribute__((address_space(3))) void*)(smem + (SLOT) * TR_STAGE + pc * 1024), 16, 0, TR_AUX);        \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pb[u],                       \
-                                             (__attribute__((address_space(3))) void*)(smem + (SLOT) * TR_STAGE + 8192 + pc * 1024), 16, 0, 0); \
+                                             (__attribute__((address_space(3))) void*)(smem + (SLOT) * TR_STAGE + 8192 + pc * 1024), 16, 0, TR_AUX); \
             pa[u] += stepA; pb[u] += stepB;                                                                              \
         }                                                                                                                \
     }

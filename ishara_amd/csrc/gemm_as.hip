@@ -293,7 +293,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int q = 0; q < NG; ++q) au[i][q] = *reinterpret_cast<const as_u32x4*>(aux + eoff[i] + n0 + 4 * GW * q);
+                for (int q = 0; q < NG; ++q) au[i][q] = __builtin_nontemporal_load(reinterpret_cast<const as_u32x4*>(aux + eoff[i] + n0 + 4 * GW * q));      // last use of a saved pre-activation
         }
         if (s + R - 1 < nsteps && !(dbg & 8)) issue(slot == 0 ? (R - 1) * STAGE : slot - STAGE);
         // ---- MFMA: acc[j][i] = sum_k Bt[row(j), k] * A[16i + .., k]
