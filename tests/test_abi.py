@@ -96,3 +96,17 @@ def test_workspace_plan_has_no_overlap(guard, monkeypatch):
         m = Model(make_config(**kw), device=None)
         n = m._lib.ishara_workspace_plan_check(m._h)
         assert n > 100, _lib.load().ishara_last_error()
+
+
+def test_c_caller_walks_the_abi(tmp_path):
+    """include/ishara_hip.h compiles as C and a plain C program (gcc + dlopen, no torch, no C++) creates the three families, reads the
+    parameter layout and audits the workspace plan through the exported symbols."""
+    import subprocess
+    exe = str(tmp_path / "abi_walk")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_walk.c"), "-ldl", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 3 and "7577784 parameters" in lines[0] and lines[2].startswith("family 2")
