@@ -950,6 +950,7 @@ const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int
 int g_force_regstage = 0;   // NT kernel choice: 0 A-stationary kernel (gemm_as.hip) where it applies, else the 128x128 LDS-DMA tile kernel; 3 tile kernel only; 2 LDS-DMA 64x128 kernel; 1 register-staged
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
 int launch_gemm_nt_as(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s);
+int launch_gemm_nt_as_f16(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s);
 int g_dbg_tn = 0;           // ablation bits for the TN kernel: 1 skip MFMA, 2 skip LDS stores, 4 skip global loads
 
 int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C,
@@ -961,8 +962,13 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
     if (ea.mode == EPI_QKV && (ea.T % 8 != 0 || N % 8 != 0 || ea.dh % 8 != 0)) {
         ishara_set_error("gemm_nt: QKV split needs T, dh multiples of 8 (T=%d dh=%d)", ea.T, ea.dh); return -1;
     }
-    if (dtM == DT_F16) {          // inference-only storage type: the register-staged 128x128 tile kernel with the f16 MFMA
+    if (dtM == DT_F16) {          // inference-only storage type: the A-stationary kernel (gemm_as_f16.hip) where it applies, else the register-staged 128x128 tile kernel
         if (op != OP_NONE) { ishara_set_error("gemm_nt: f16 operands take no operand transform"); return -1; }
+        if (dtA == DT_F16 && g_force_regstage == 0 && K % 32 == 0 && ldb % 64 == 0 && ((uintptr_t)A) % 16 == 0) {
+            const int rc = launch_gemm_nt_as_f16(dtC, A, Bt, C, M, N, K, ldb, ea, s);
+            if (rc != 1) return rc;
+        }
+        if (ea.ln_gamma || ea.pa_P) { ishara_set_error("gemm_nt: f16 operand prologue on a shape the A-stationary kernel does not take"); return -1; }
         if (dtA == DT_F16 && dtC == DT_F16) return run_nt<f16, f16, f16, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
         if (dtA == DT_F32 && dtC == DT_F16) return run_nt<float, f16, f16, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);
         if (dtA == DT_F16 && dtC == DT_F32) return run_nt<f16, f16, float, OP_NONE>(A, Bt, C, M, N, K, ldb, oa, ea, s);

@@ -28,6 +28,22 @@
 #include "common.h"
 #include "kernels.h"
 
+// The 16-bit operand type of this translation unit: bf16 here; gemm_as_f16.hip includes this file again with AS_F16 defined for the
+// fp16 inference path (ISHARA_F16).  Only the forward instantiations exist there.
+#ifdef AS_F16
+typedef f16 as_t;
+typedef f16x8 as_v8;
+#define AS_MFMA(b, a, acc) __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, acc, 0, 0, 0)
+#define AS_DT DT_F16
+#define AS_NAME(x) x##_f16
+#else
+typedef bf16 as_t;
+typedef bf16x8 as_v8;
+#define AS_MFMA(b, a, acc) __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0)
+#define AS_DT DT_BF16
+#define AS_NAME(x) x
+#endif
+
 extern int g_force_regstage;
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
 
@@ -49,16 +65,20 @@ template <int GW, typename T> DEVI void as_st(T* p, const float (&v)[GW]) {
 // the same with the non-temporal hint: tensors that are only read again in the BACKWARD pass (saved pre-activations, the prologues'
 // transformed rows) should not push the tensors the next launch reads out of L2 / Infinity Cache
 template <int GW, typename T> DEVI void as_st_nt(T* p, const float (&v)[GW]) {
-    if constexpr (GW == 8 && is_bf16_t<T>::value) {
-        bf16x8 t;
+    if constexpr (GW == 8 && is_16b_t<T>::value) {
+        as_v8 t;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
-        __builtin_nontemporal_store(t, reinterpret_cast<bf16x8*>(p));
+        for (int i = 0; i < 8; ++i) t[i] = (as_t)v[i];
+        __builtin_nontemporal_store(t, reinterpret_cast<as_v8*>(p));
     } else as_st<GW>(p, v);
 }
 // 16 bytes of TC -> GW floats (8 bf16 / 4 f32)
 template <typename TC, int GW> DEVI void as_unpack(const as_u32x4& r, float (&v)[GW]) {
-    if constexpr (GW == 8) {
+    if constexpr (GW == 8 && std::is_same<TC, f16>::value) {
+        const f16x8 h = __builtin_bit_cast(f16x8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    } else if constexpr (GW == 8) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) { v[2 * h] = __uint_as_float(r[h] << 16); v[2 * h + 1] = __uint_as_float(r[h] & 0xffff0000u); }
     } else {
@@ -80,7 +100,7 @@ template <int MASK, int F> DEVI bool as_on(bool runtime) {
 // PRO: operand prologue — 0 none, 1 LayerNorm over K (ea.ln_*), 2 per-sample affine (ea.pa_*); both write the transformed rows to
 // ea.pro_out when it is set.  The coefficient vectors are staged in the ring slot the DMA fills last (free until step 0's issue).
 template <typename TC, int KT, int MASK, int RT, int DBG, int PRO, int NW = 4>
-DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, const EpiArgs& ea,
+DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, const EpiArgs& ea,
                   char* smem, const float* bias_s, int m_base) {
     constexpr int RB = KT * 64;                    // bytes of one staged weight row (full K)
     constexpr int NS = AS_NS;                      // output columns per step
@@ -88,7 +108,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
     constexpr int R = KT <= 8 ? 3 : 2;             // ring depth: 48 KB / 64 KB of LDS
     constexpr int K = KT * 32;
     constexpr int DPW = STAGE / 1024 / NW;         // 1 KB DMA instructions per wave per stage (NW waves per workgroup)
-    constexpr bool PAIR = is_bf16_t<TC>::value;    // pair MFMA tiles so that a lane owns 8 consecutive columns (16-byte bf16 accesses)
+    constexpr bool PAIR = is_16b_t<TC>::value;     // pair MFMA tiles so that a lane owns 8 consecutive columns (16-byte bf16 accesses)
     constexpr int GW = PAIR ? 8 : 4;               // columns per lane per group
     constexpr int NG = NS / (4 * GW);              // groups per row tile per step: 1 (bf16 C) / 2 (f32 C)
     constexpr int SPS = RT * NG;                   // stores per lane per step
@@ -113,7 +133,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 
     // weight DMA: instruction u = wid*DPW + t moves bytes [u*1024, +1024) of the stage; 16-byte chunk p of row r holds
     // source chunk p ^ as_swz(r) (swizzle on the source address: the LDS image of an LDS-DMA is lane-linear)
-    const bf16* bsrc[DPW];
+    const as_t* bsrc[DPW];
 #pragma unroll
     for (int t = 0; t < DPW; ++t) {
         const int o = (wid * DPW + t) * 1024 + lane * 16;
@@ -134,12 +154,12 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
         if (st < nsteps && !(dbg & 8)) issue(st * STAGE);       // dbg: ablation bits of tools/gemm_ablate.py (1 no epilogue, 2 no MFMA, 4 no LDS reads, 8 no DMA)
 
     // A fragments: lane (c, g) holds row 16i + c, k = 32kt + 8g .. +7
-    bf16x8 a[RT][KT];
+    as_v8 a[RT][KT];
     int mrow[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         mrow[i] = min(mw + 16 * i + c, M - 1);
-        const bf16x8* p = reinterpret_cast<const bf16x8*>(A + (size_t)mrow[i] * K + g * 8);
+        const as_v8* p = reinterpret_cast<const as_v8*>(A + (size_t)mrow[i] * K + g * 8);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) a[i][kt] = p[kt * 4];
     }
@@ -153,10 +173,10 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
         __syncthreads();
         // Every pass over the fragments unpacks them again from the packed registers, behind an opaque asm: otherwise hipcc keeps
         // all 8*KT*RT unpacked floats alive across the three passes (statistics, variance, normalise) and spills hundreds of VGPRs.
-        auto unpack = [&](const bf16x8& f, float (&v)[8]) {
+        auto unpack = [&](const as_v8& f, float (&v)[8]) {
             as_u32x4 t = __builtin_bit_cast(as_u32x4, f);
             asm volatile("" : "+v"(t));
-            as_unpack<bf16, 8>(t, v);
+            as_unpack<as_t, 8>(t, v);
         };
         float mean[RT], rstd[RT];
 #pragma unroll
@@ -203,9 +223,9 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
             for (int i = 0; i < RT; ++i) {
                 float v[8];
                 unpack(a[i][kt], v);
-                bf16x8 t;
+                as_v8 t;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = (bf16)(PRO == 1 ? (v[e] - mean[i]) * rstd[i] * wv[e] + bv[e] : v[e] * wv[e] + bv[e]);
+                for (int e = 0; e < 8; ++e) t[e] = (as_t)(PRO == 1 ? (v[e] - mean[i]) * rstd[i] * wv[e] + bv[e] : v[e] * wv[e] + bv[e]);
                 a[i][kt] = t;
             }
         }
@@ -214,7 +234,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
             for (int i = 0; i < RT; ++i) {
                 const int m = mw + 16 * i + c;
                 if (m < M) {
-                    bf16x8* p = reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(ea.pro_out) + (size_t)m * K + g * 8);
+                    as_v8* p = reinterpret_cast<as_v8*>(reinterpret_cast<as_t*>(ea.pro_out) + (size_t)m * K + g * 8);
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) __builtin_nontemporal_store(a[i][kt], &p[kt * 4]);
                 }
@@ -262,7 +282,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
         for (int kt = 0; kt < KT; ++kt) {
             as_u32x4 t = __builtin_bit_cast(as_u32x4, a[i][kt]);
             asm volatile("" : "+v"(t));
-            a[i][kt] = __builtin_bit_cast(bf16x8, t);
+            a[i][kt] = __builtin_bit_cast(as_v8, t);
         }
         asm volatile("" : "+v"(rsc[i]));
     }
@@ -308,9 +328,9 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(st + ((kt & 1) ? off_o : off_e) + (kt >> 1) * 128 + j * JSTRIDE);
+                    const as_v8 b = *reinterpret_cast<const as_v8*>(st + ((kt & 1) ? off_o : off_e) + (kt >> 1) * 128 + j * JSTRIDE);
 #pragma unroll
-                    for (int i = 0; i < RT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i][kt], acc[j][i], 0, 0, 0);
+                    for (int i = 0; i < RT; ++i) acc[j][i] = AS_MFMA(b, a[i][kt], acc[j][i]);
                 }
             }
         } else if (!(dbg & 4)) {       // LDS reads only
@@ -322,13 +342,13 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
                     acc[j][0] += b;
                 }
         } else if (!(dbg & 2)) {       // MFMA only
-            const bf16x8 b = a[0][0];
+            const as_v8 b = a[0][0];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < RT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i][kt], acc[j][i], 0, 0, 0);
+                    for (int i = 0; i < RT; ++i) acc[j][i] = AS_MFMA(b, a[i][kt], acc[j][i]);
         } else {
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[0][i][0] = (float)a[i][0][0] + (float)a[i][KT - 1][7];
@@ -428,7 +448,7 @@ DEVI void as_pass(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* _
 // VGPRs, so only 2 workgroups fit per CU; 192-row workgroups (512 at M = 98304, again exactly one round) run as a
 // 128-row pass followed by a 64-row pass.
 template <typename TC, int KT, int MASK, int DBG = 0, int PRO = 0>
-__global__ __launch_bounds__(KT <= 16 ? 256 : 512, KT <= 8 ? 3 : (KT <= 16 ? 2 : 1)) void gemm_nt_as_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bt, TC* __restrict__ C,
+__global__ __launch_bounds__(KT <= 16 ? 256 : 512, KT <= 8 ? 3 : (KT <= 16 ? 2 : 1)) void gemm_nt_as_kernel(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* __restrict__ C,
                                                                          int M, int N, int ldb, EpiArgs ea) {
     constexpr int R = KT <= 8 ? 3 : 2;
     constexpr int STAGE = AS_NS * KT * 64;
@@ -469,7 +489,7 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
     }
 }
 
-#define AS_LAUNCH(MASK) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK>), grid, block, 0, s, (const bf16*)A, (const bf16*)Bt, (TC*)C, M, N, ldb, ea)
+#define AS_LAUNCH(MASK) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
 template <typename TC, int KT>
 static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea, hipStream_t s) {
     constexpr int BR = KT <= 8 ? 128 : (KT <= 16 ? 192 : 128);     // rows per workgroup
@@ -480,8 +500,8 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     while (gy < 4 && gx * gy * 2 <= slots && (N / AS_NS) % (gy * 2) == 0 && N / (gy * 2) >= 128) gy *= 2;
     const dim3 grid(gx, gy), block(KT <= 16 ? 256 : 512);
     const int mask = as_mask_of(ea);
-    if constexpr (is_bf16_t<TC>::value && KT >= 8) {
-#define AS_PRO(MASK, PRO) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK, 0, PRO>), grid, block, 0, s, (const bf16*)A, (const bf16*)Bt, (TC*)C, M, N, ldb, ea)
+    if constexpr (is_16b_t<TC>::value && KT >= 8) {
+#define AS_PRO(MASK, PRO) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK, 0, PRO>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
         if (ea.ln_gamma) {           // LayerNorm prologue: the GEMMs that consume a LayerNorm output (FFN expand, QKV, conv-module expand)
             if (gy != 1) { ishara_set_error("gemm_nt_as: prologue with split columns"); return -1; }
             switch (mask) {
@@ -506,11 +526,25 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     }
     if constexpr (KT == 4) {
         if (mask == AS_DACT) AS_LAUNCH(AS_DACT); else if (mask == (AS_DACT | AS_DROP)) AS_LAUNCH(AS_DACT | AS_DROP); else AS_LAUNCH(AS_ALL);
-    } else if constexpr (is_bf16_t<TC>::value) {
+    }
+#ifdef AS_F16
+    else if constexpr (is_16b_t<TC>::value) {      // fp16 = inference: the forward passes' combinations, everything else through AS_ALL
+        switch (mask) {
+            case 0: AS_LAUNCH(0); break;
+            case AS_RESID: AS_LAUNCH(AS_RESID); break;
+            case AS_ACT | AS_PREOUT: AS_LAUNCH(AS_ACT | AS_PREOUT); break;
+            case AS_ACT: AS_LAUNCH(AS_ACT); break;
+            case AS_QKV: AS_LAUNCH(AS_QKV); break;
+            case AS_ADDTAB: AS_LAUNCH(AS_ADDTAB); break;
+            default: AS_LAUNCH(AS_ALL); break;
+        }
+    }
+#else
+    else if constexpr (is_16b_t<TC>::value) {
         // the feature combinations the encoder's forward / backward passes use (model.hip), compiled without the others
         switch (mask) {
             case 0:
-                if (ea.dbg) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, 0, 1>), grid, block, 0, s, (const bf16*)A, (const bf16*)Bt, (TC*)C, M, N, ldb, ea);
+                if (ea.dbg) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, 0, 1>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea);
                 else AS_LAUNCH(0);
                 break;
             case AS_RESID: AS_LAUNCH(AS_RESID); break;                                           // W2 / Wb / Wp eval, dgrad + skip gradient
@@ -527,15 +561,18 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
             case AS_ADDTAB: AS_LAUNCH(AS_ADDTAB); break;
             default: AS_LAUNCH(AS_ALL); break;
         }
-    } else {
+    }
+#endif
+    else {
         if (mask == 0) AS_LAUNCH(0); else AS_LAUNCH(AS_ALL);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 #undef AS_LAUNCH
 
+#ifndef AS_F16
 bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
-    if (dtA != DT_BF16 || dtM != DT_BF16 || dtC != DT_BF16 || (K != 256 && K != 512 && K != 1024) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
+    if (!dt_is16(dtA) || dtM != dtA || dtC != dtA || (K != 256 && K != 512 && !(K == 1024 && dtA == DT_BF16)) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
     if (ldb % 64 != 0 || g_force_regstage) return false;
     const int BR = K == 256 ? 128 : (K == 512 ? 192 : 128), gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : (K == 512 ? 512 : 256);
     if (gx * 2 <= slots && (N / AS_NS) % 2 == 0 && N / 2 >= 128) return false;      // the launcher would split the columns: every split would redo (and rewrite) the prologue
@@ -546,7 +583,7 @@ bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int 
 }
 
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
-    if (K != 256 && K != 512 && !((K == 128 || K == 1024) && dtC == DT_BF16)) return false;
+    if (K != 256 && K != 512 && !((K == 128 || K == 1024) && dtC == DT_BF16)) return false;      // fp16 operands (dtC DT_F16 / DT_F32 from gemm_as_f16.hip): K 256 / 512
     if (N % AS_NS != 0 || N > AS_MAXN || ldb < K || ldb % 8 != 0 || M < 1) return false;
     if (ea.mode == EPI_QKV && (ea.dh % 8 != 0 || ea.T % 8 != 0)) return false;
     return true;
@@ -568,10 +605,20 @@ const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea) {
     return it->second.c_str();
 }
 
+#endif   // !AS_F16
+
 // returns 1 when the shape is not one this kernel takes (caller falls through to the tile kernels)
+#ifdef AS_F16
+int launch_gemm_nt_as_f16(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s) {
+    if ((K != 256 && K != 512) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return 1;
+    if (dtC == DT_F16) return K == 256 ? run_as<f16, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<f16, 16>(A, Bt, C, M, N, ldb, ea, s);
+    return K == 256 ? run_as<float, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<float, 16>(A, Bt, C, M, N, ldb, ea, s);
+}
+#else
 int launch_gemm_nt_as(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s) {
     if (!gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return 1;
     if (dtC == DT_BF16) return K == 128 ? run_as<bf16, 4>(A, Bt, C, M, N, ldb, ea, s) : (K == 256 ? run_as<bf16, 8>(A, Bt, C, M, N, ldb, ea, s) :
                                (K == 512 ? run_as<bf16, 16>(A, Bt, C, M, N, ldb, ea, s) : run_as<bf16, 32>(A, Bt, C, M, N, ldb, ea, s)));
     return K == 256 ? run_as<float, 8>(A, Bt, C, M, N, ldb, ea, s) : run_as<float, 16>(A, Bt, C, M, N, ldb, ea, s);
 }
+#endif
