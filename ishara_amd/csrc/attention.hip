@@ -239,9 +239,12 @@ int launch_attn_bwd_mfma(const void* q, const void* k, const void* vt, const voi
 int launch_attn_fwd_mfma(const void* q, const void* k, const void* vt, void* o, float* lse,
                          int B, int H, int T, int dh, float scale, DropSpec drop, uint32_t* maskbits, hipStream_t s);
 
+int launch_attn_fwd_mfma_f16(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int T, int dh, float scale, hipStream_t s);
+
 int launch_attn_fwd(int dt, const void* q, const void* k, const void* vt, void* o, float* lse,
                     int B, int H, int T, int dh, float scale, DropSpec drop, int impl, uint32_t* maskbits, hipStream_t s) {
     if (impl == 1 && dt == DT_BF16 && (dh == 32 || dh == 64)) return launch_attn_fwd_mfma(q, k, vt, o, lse, B, H, T, dh, scale, drop, maskbits, s);
+    if (impl == 1 && dt == DT_F16 && (dh == 32 || dh == 64) && drop.thr == 0 && T % 8 == 0) return launch_attn_fwd_mfma_f16(q, k, vt, o, lse, B, H, T, dh, scale, s);
     if (dt == DT_BF16) { ATT_DISPATCH(attn_fwd_kernel, bf16, (const bf16*)q, (const bf16*)k, (const bf16*)vt, (bf16*)o, lse, B, H, T, scale, drop); }
     else if (dt == DT_F16) { ATT_DISPATCH(attn_fwd_kernel, f16, (const f16*)q, (const f16*)k, (const f16*)vt, (f16*)o, lse, B, H, T, scale, drop); }
     else { ATT_DISPATCH(attn_fwd_kernel, float, (const float*)q, (const float*)k, (const float*)vt, (float*)o, lse, B, H, T, scale, drop); }

@@ -40,15 +40,29 @@ DEVI void attn_block_of(int nxb, int BH, int& bh, int& xb) {
 
 // DM: dropout mode, compile-time so that no per-score uniform branch is left: 0 none, 1 counter hash, 2 counter hash in the
 // forward + keep bits cached in `maskbits` for the two backward kernels
-template <int DH, int DM>
-__global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ vt,
-                                                            bf16* __restrict__ o, float* __restrict__ lse, int H, int Tn, float scale, DropSpec drop, int BH, uint32_t* __restrict__ maskbits) {
+template <typename E> struct af_vec;
+template <> struct af_vec<bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct af_vec<f16> { typedef f16x8 v8; typedef __attribute__((ext_vector_type(4))) _Float16 v4; };
+DEVI f32x4 af_mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+DEVI f32x4 af_mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+template <typename E> DEVI uint32_t pk2e(float lo, float hi);
+template <> DEVI uint32_t pk2e<bf16>(float lo, float hi) { return pk2(lo, hi); }
+template <> DEVI uint32_t pk2e<f16>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+    f16x2 t; t[0] = (f16)lo; t[1] = (f16)hi;
+    return __builtin_bit_cast(uint32_t, t);
+}
+
+// E: element type of q, k, v^T and o — bf16 (training and inference) or f16 (the ISHARA_F16 inference path, dropout-free)
+template <int DH, int DM, typename E = bf16>
+__global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(const E* __restrict__ q, const E* __restrict__ k, const E* __restrict__ vt,
+                                                            E* __restrict__ o, float* __restrict__ lse, int H, int Tn, float scale, DropSpec drop, int BH, uint32_t* __restrict__ maskbits) {
     constexpr int KS = DH / 32;      // MFMA k-steps over the head dimension
     constexpr int DT = DH / 16;      // 16-wide output (dv) tiles
     constexpr int NP = DH / 32;      // 16-byte pieces per thread per staged operand (64*DH*2 B / 4 KB)
     constexpr int KLD = DH + AF_PAD;
-    __shared__ __attribute__((aligned(16))) bf16 Ks[2][AF_KC * KLD];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[2][DH * AF_VLD];
+    __shared__ __attribute__((aligned(16))) E Ks[2][AF_KC * KLD];
+    __shared__ __attribute__((aligned(16))) E Vs[2][DH * AF_VLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     int bh, xb;
@@ -56,16 +70,16 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
     attn_block_of(nqb, BH, bh, xb);
     const int b = bh / H, h = bh - b * H;
     const int qbase = xb * AF_QB + wid * 32;
-    const bf16* qb = q + (size_t)bh * Tn * DH;
-    const bf16* kb = k + (size_t)bh * Tn * DH;
-    const bf16* vb = vt + (size_t)bh * DH * Tn;
+    const E* qb = q + (size_t)bh * Tn * DH;
+    const E* kb = k + (size_t)bh * Tn * DH;
+    const E* vb = vt + (size_t)bh * DH * Tn;
 
-    bf16x8 qf[2][KS];
+    typename af_vec<E>::v8 qf[2][KS];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int qrow = min(qbase + 16 * t + c, Tn - 1);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) qf[t][s] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * DH + 32 * s + 8 * g);
+        for (int s = 0; s < KS; ++s) qf[t][s] = *reinterpret_cast<const typename af_vec<E>::v8*>(qb + (size_t)qrow * DH + 32 * s + 8 * g);
     }
     f32x4 acc_o[DT][2];
 #pragma unroll
@@ -108,26 +122,26 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
     for (int ch = 0; ch < nch; ++ch) {
         const bool more = ch + 1 < nch;
         if (more) gload(ch + 1);
-        const bf16* Kc = Ks[ch & 1];
-        const bf16* Vc = Vs[ch & 1];
+        const E* Kc = Ks[ch & 1];
+        const E* Vc = Vs[ch & 1];
         const int key0 = ch * AF_KC;
         const bool partial = key0 + AF_KC > Tn;      // only the last chunk needs per-key bounds masks
         // ---- S^T tiles: 4 key tiles x 2 query tiles
         f32x4 sacc[4][2];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            bf16x8 kf[KS];
+            typename af_vec<E>::v8 kf[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(Kc + (16 * kt + c) * KLD + 32 * s + 8 * g);
+            for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const typename af_vec<E>::v8*>(Kc + (16 * kt + c) * KLD + 32 * s + 8 * g);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 sacc[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < KS; ++s) sacc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[t][s], sacc[kt][t], 0, 0, 0);
+                for (int s = 0; s < KS; ++s) sacc[kt][t] = af_mfma(kf[s], qf[t][s], sacc[kt][t]);
             }
         }
         // ---- online softmax per query tile; lane = (query c, keys 16kt + 4g + r)
-        bf16x8 pb[2][2];
+        typename af_vec<E>::v8 pb[2][2];
         uint32_t keepbits = 0u;          // bit 16t + 4kt + r: dropout keep flag of (query tile t, key 16kt + 4g + r)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -168,9 +182,9 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 w;
-                w.x = pk2(p[2 * ks][0], p[2 * ks][1]);         w.y = pk2(p[2 * ks][2], p[2 * ks][3]);
-                w.z = pk2(p[2 * ks + 1][0], p[2 * ks + 1][1]); w.w = pk2(p[2 * ks + 1][2], p[2 * ks + 1][3]);
-                pb[t][ks] = __builtin_bit_cast(bf16x8, w);
+                w.x = pk2e<E>(p[2 * ks][0], p[2 * ks][1]);         w.y = pk2e<E>(p[2 * ks][2], p[2 * ks][3]);
+                w.z = pk2e<E>(p[2 * ks + 1][0], p[2 * ks + 1][1]); w.w = pk2e<E>(p[2 * ks + 1][2], p[2 * ks + 1][3]);
+                pb[t][ks] = __builtin_bit_cast(typename af_vec<E>::v8, w);
             }
         }
         if constexpr (DM == 2) __builtin_nontemporal_store(keepbits, &maskbits[((size_t)(bh * nqb + xb) * nch + ch) * 256 + tid]);      // read again only by the backward pass
@@ -179,12 +193,12 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const bf16* vrow = Vc + (16 * d + c) * AF_VLD + 32 * ks + 4 * g;
+                const E* vrow = Vc + (16 * d + c) * AF_VLD + 32 * ks + 4 * g;
                 const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
                 const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 16);
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, (u32x4){lo.x, lo.y, hi.x, hi.y});
+                const typename af_vec<E>::v8 vf = __builtin_bit_cast(typename af_vec<E>::v8, (u32x4){lo.x, lo.y, hi.x, hi.y});
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc_o[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[t][ks], acc_o[d][t], 0, 0, 0);
+                for (int t = 0; t < 2; ++t) acc_o[d][t] = af_mfma(vf, pb[t][ks], acc_o[d][t]);
             }
         if (more) lstore((ch + 1) & 1);
         __syncthreads();
@@ -199,13 +213,13 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
         const int qrow = qbase + 16 * t + c;
         if (qrow < Tn) {
             const float inv = (DM != 0 ? drop.scale : 1.f) / l;
-            bf16* orow = o + ((size_t)b * Tn + qrow) * dmodel + h * DH;
+            E* orow = o + ((size_t)b * Tn + qrow) * dmodel + h * DH;
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                bf16x4 w;
+                typename af_vec<E>::v4 w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = (bf16)(acc_o[d][t][r] * inv);
-                *reinterpret_cast<bf16x4*>(orow + 16 * d + 4 * g) = w;
+                for (int r = 0; r < 4; ++r) w[r] = (E)(acc_o[d][t][r] * inv);
+                *reinterpret_cast<typename af_vec<E>::v4*>(orow + 16 * d + 4 * g) = w;
             }
             if (g == 0) lse[(size_t)bh * Tn + qrow] = m_run[t] * scale + __logf(l);
         }
@@ -917,6 +931,17 @@ int launch_attn_bwd_mfma(const void* q, const void* k, const void* vt, const voi
 }
 
 size_t attn_mask_words(int B, int H, int T) { return (size_t)B * H * ((T + AF_QB - 1) / AF_QB) * ((T + AF_KC - 1) / AF_KC) * 256; }
+
+// fp16 operands (inference, no dropout)
+int launch_attn_fwd_mfma_f16(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int T, int dh, float scale, hipStream_t s) {
+    if (T % 8 != 0) { ishara_set_error("attn_fwd_mfma: T %% 8 != 0"); return -1; }
+    dim3 grid(((T + AF_QB - 1) / AF_QB) * B * H);
+    const DropSpec nodrop{0u, 0u, 1.f};
+    if (dh == 32) hipLaunchKernelGGL((attn_fwd_mfma_kernel<32, 0, f16>), grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)vt, (f16*)o, lse, H, T, scale, nodrop, B * H, (uint32_t*)nullptr);
+    else if (dh == 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<64, 0, f16>), grid, dim3(256), 0, s, (const f16*)q, (const f16*)k, (const f16*)vt, (f16*)o, lse, H, T, scale, nodrop, B * H, (uint32_t*)nullptr);
+    else { ishara_set_error("attn_fwd_mfma: head dim %d unsupported (32, 64)", dh); return -1; }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int launch_attn_fwd_mfma(const void* q, const void* k, const void* vt, void* o, float* lse,
                          int B, int H, int T, int dh, float scale, DropSpec drop, uint32_t* maskbits, hipStream_t s) {
