@@ -503,7 +503,7 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     if constexpr (is_16b_t<TC>::value && KT >= 8) {
 #define AS_PRO(MASK, PRO) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK, 0, PRO>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
         if (ea.ln_gamma) {           // LayerNorm prologue: the GEMMs that consume a LayerNorm output (FFN expand, QKV, conv-module expand)
-            if (gy != 1) { ishara_set_error("gemm_nt_as: prologue with split columns"); return -1; }
+            if (gy != 1 && (ea.pro_out || ea.ln_mean)) { ishara_set_error("gemm_nt_as: prologue side outputs with split columns"); return -1; }
             switch (mask) {
                 case 0: AS_PRO(0, 1); break;
                 case AS_ACT | AS_PREOUT: AS_PRO(AS_ACT | AS_PREOUT, 1); break;
@@ -514,7 +514,7 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
             return hipGetLastError() == hipSuccess ? 0 : -2;
         }
         if (ea.pa_P) {               // per-sample affine prologue: the project GEMM of a Conv1DBlock
-            if (gy != 1) { ishara_set_error("gemm_nt_as: prologue with split columns"); return -1; }
+            if (gy != 1 && ea.pro_out) { ishara_set_error("gemm_nt_as: prologue side outputs with split columns"); return -1; }
             switch (mask) {
                 case AS_RESID: AS_PRO(AS_RESID, 2); break;
                 case AS_RESID | AS_ROWSCALE: AS_PRO(AS_RESID | AS_ROWSCALE, 2); break;
@@ -575,7 +575,9 @@ bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int 
     if (!dt_is16(dtA) || dtM != dtA || dtC != dtA || (K != 256 && K != 512 && !(K == 1024 && dtA == DT_BF16)) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
     if (ldb % 64 != 0 || g_force_regstage) return false;
     const int BR = K == 256 ? 128 : (K == 512 ? 192 : 128), gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : (K == 512 ? 512 : 256);
-    if (gx * 2 <= slots && (N / AS_NS) % 2 == 0 && N / 2 >= 128) return false;      // the launcher would split the columns: every split would redo (and rewrite) the prologue
+    // the launcher would split the columns: every split redoes the prologue on its rows — fine when nothing is written (inference),
+    // not when the transformed rows / statistics are side outputs
+    if (gx * 2 <= slots && (N / AS_NS) % 2 == 0 && N / 2 >= 128 && (ea.pro_out || ea.ln_mean)) return false;
     const int mask = as_mask_of(ea);
     if (ea.ln_gamma) return mask == 0 || mask == (AS_ACT | AS_PREOUT) || mask == (AS_ACT | AS_PREOUT | AS_DROP) || mask == AS_QKV;
     if (ea.pa_P) return ea.T > 0 && ea.T % BR == 0 && (mask == AS_RESID || mask == (AS_RESID | AS_ROWSCALE));   // a workgroup's rows inside one sample

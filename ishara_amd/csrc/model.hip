@@ -492,13 +492,13 @@ static const void* ln_prologue(ishara_model* m, const DenseW& w, const Run& r, c
     *rc = 0;
     EpiArgs probe = ea;
     probe.ln_gamma = m->P(ln.gamma); probe.ln_beta = m->P(ln.beta);
+    probe.ln_mean = r.training ? m->Wf(mean) : nullptr; probe.pro_out = r.training ? m->W(xn) : nullptr;     // inference: no side outputs
     if (gemm_nt_as_prologue_ok(m->dt, m->dt, m->dt, r.M, w.N, w.K, w.ldt, probe)) {
         ea.ln_gamma = m->P(ln.gamma); ea.ln_beta = m->P(ln.beta); ea.ln_eps = eps;
-        ea.ln_mean = m->Wf(mean); ea.ln_rstd = m->Wf(rstd);
-        ea.pro_out = r.training ? m->W(xn) : nullptr;
+        ea.ln_mean = probe.ln_mean; ea.ln_rstd = r.training ? m->Wf(rstd) : nullptr;
+        ea.pro_out = probe.pro_out;
         return x;
     }
-    ProfRec* _pr = nullptr; (void)_pr;
     *rc = [&]() -> int {
         CKP(m, "layernorm_fwd", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_fwd(m->dt, x, m->P(ln.gamma), m->P(ln.beta), eps, m->W(xn), m->Wf(mean), m->Wf(rstd), r.M, m->d, m->s));
         return 0;
@@ -533,6 +533,7 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     // the transformed fragments for the weight-gradient GEMM (training only); other shapes run the separate affine pass
     {
         EpiArgs probe = e2; probe.pa_P = m->Wf(cb.P); probe.pa_Q = m->Wf(cb.Q); probe.T = T; probe.bias = m->P(cb.W2.b);
+        probe.pro_out = r.training ? m->W(cb.h4) : nullptr;
         if (gemm_nt_as_prologue_ok(dt, dt, dt, r.M, cb.W2.N, cb.W2.K, cb.W2.ldt, probe)) {
             e2.pa_P = m->Wf(cb.P); e2.pa_Q = m->Wf(cb.Q); e2.T = T; e2.pro_out = r.training ? m->W(cb.h4) : nullptr;
             CK(gemm_fwd(m, cb.W2, m->W(cb.h2), dt, m->W(cb.out), dt, r.M, OP_NONE, no, e2));
