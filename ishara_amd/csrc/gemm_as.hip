@@ -229,17 +229,6 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
                 a[i][kt] = t;
             }
         }
-        if (ea.pro_out) {
-#pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                const int m = mw + 16 * i + c;
-                if (m < M) {
-                    as_v8* p = reinterpret_cast<as_v8*>(reinterpret_cast<as_t*>(ea.pro_out) + (size_t)m * K + g * 8);
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) __builtin_nontemporal_store(a[i][kt], &p[kt * 4]);
-                }
-            }
-        }
         __syncthreads();                     // the coefficient slot is free again before any wave reaches step 0's DMA issue
     }
 
@@ -441,6 +430,21 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
             }
         }
         slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE;
+    }
+    // the prologue's transformed rows, for the backward pass: stored AFTER the column loop (the fragments are still in registers), so
+    // that these stores do not sit in front of the loop's counted vmcnt waits and drain beside other workgroups' loops
+    if constexpr (PRO != 0) {
+        if (ea.pro_out) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int m = mw + 16 * i + c;
+                if (m < M) {
+                    as_v8* p = reinterpret_cast<as_v8*>(reinterpret_cast<as_t*>(ea.pro_out) + (size_t)m * K + g * 8);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) __builtin_nontemporal_store(a[i][kt], &p[kt * 4]);
+                }
+            }
+        }
     }
 }
 

@@ -16,7 +16,7 @@ CFG2 = dict(dim=256, num_conv_squeeze_blocks=2, num_conv_conform_blocks=2, kerne
 CFG4 = dict(dim=512, num_conv_squeeze_blocks=6, num_conv_conform_blocks=6, kernel_sizes=[11, 5, 3], num_conv_per_block=3,
             num_heads=8, expansion_factor=2, transformer_kernel_size=15, input_shape=(512, 224), B=2)
 # 48 modules deep (36 Conv1DBlocks + 12 transformer blocks), ~250 chained bf16 activations
-CFG4_BF16_TOL = dict(BF16_TOL, logits=0.3, grad=0.2, grad_small=0.35, loss=3e-2)
+CFG4_BF16_TOL = dict(BF16_TOL, logits=0.3, grad=0.2, grad_small=0.35, loss=5e-3)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -82,7 +82,7 @@ def _log_observed(rec):
 
 
 # bf16 tolerances by model depth: observed errors grow with the number of chained bf16 activations
-BF16_TOL = dict(logits=0.15, loss=2e-2, grad=0.12, grad_small=0.2, stats=3e-2)
+BF16_TOL = dict(logits=0.15, loss=5e-3, grad=0.12, grad_small=0.2, stats=3e-2)   # observed on configs[1] / [3]: logits 0.07 / 0.13, loss 1.6e-4, gradients rel-L2 0.11 / 0.14
 
 
 def check_train_step(kw, dtype, dropout, tag, bf16_tol=BF16_TOL, check_decode=False):
