@@ -1226,16 +1226,56 @@ DEVI void tr_wait(TrFrags& f) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]));
 }
 
+// The slab sums of the PREVIOUS weight-gradient GEMM ride along as extra workgroups of the next one (blockIdx.x >= nmain): the sums are
+// ~5 us kernels that leave the chip idle, 59 of them per step; here they run beside the GEMM's workgroups (two slab buffers alternate).
+struct TnRed { const float* slab; float* out0; float* out1; int n0, n, splits; size_t stride; int nb, nbv, nmain; };
+DEVI void tn_reduce_block(const TnRed& r, int rb, int nrb, float4 (*red)[32]) {
+    constexpr int SL = 8, CQ = 32;                       // the layout of reduce_slabs_cols_kernel<8, 32>
+    const int tid = threadIdx.x, cq = tid % CQ, sl = tid / CQ;
+    for (int grp = rb; grp * (CQ * 4) < r.n; grp += nrb) {
+        const int col = grp * (CQ * 4) + cq * 4;
+        const int cin = r.nb ? (col < r.n0 ? col % r.nb : col - r.n0) : 0;
+        const bool valid = col < r.n && (r.nb == 0 || cin < r.nbv);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            for (int s0 = sl; s0 < r.splits; s0 += SL * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sidx = s0 + SL * u;
+                    v[u] = sidx < r.splits ? *reinterpret_cast<const float4*>(r.slab + (size_t)sidx * r.stride + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+        }
+        red[sl][cq] = acc;
+        __syncthreads();
+        if (sl == 0 && valid) {
+            float4 t = red[0][cq];
+#pragma unroll
+            for (int w = 1; w < SL; ++w) { t.x += red[w][cq].x; t.y += red[w][cq].y; t.z += red[w][cq].z; t.w += red[w][cq].w; }
+            float* dst = col < r.n0 ? (r.nb ? r.out0 + (size_t)(col / r.nb) * r.nbv + cin : r.out0 + col) : r.out1 + (col - r.n0);
+            dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;
+        }
+        __syncthreads();
+    }
+}
+
 template <int DBG, bool BRS = false>      // DBG = 1: the ablation bits of tools/gemm_ablate.py are honoured (kept out of the production loop); BRS: weighted bias sum
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                          float* __restrict__ out, float* __restrict__ dbias,
                                                          int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, int dbg,
-                                                         const float* __restrict__ brs, int brsT) {
+                                                         const float* __restrict__ brs, int brsT, TnRed prev) {
     // brs != nullptr: the bias gradient is the column sum of brs[m / brsT] * B[m,:] (drop-path scale of the sample a row belongs to;
     // brsT % 32 == 0, so the 32 rows of a stage share it)
     // slab layout: [split][Ka*Nb weight partial | Nb bias partial] so that ONE reduction launch sums both
     const size_t sstride = (size_t)Ka * Nb + Nb;
     __shared__ __attribute__((aligned(16))) char smem[TR_NSTAGE * TR_STAGE];
+    if (prev.nmain > 0 && (int)blockIdx.x >= prev.nmain) {        // a rider: sums a slice of the previous launch's slabs
+        tn_reduce_block(prev, (int)blockIdx.x - prev.nmain, (int)gridDim.x - prev.nmain, reinterpret_cast<float4 (*)[32]>(smem));
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
@@ -1546,7 +1586,7 @@ int g_tn_blocks = 0;
 int g_tn_phase = 0;            // 0: GEMM + slab sums; 1: GEMM kernel only; 2: slab sums only (the model profiles the two separately)
 
 static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s, int ka_valid, int nb_valid,
-                     const float* brs, int brsT) {
+                     const float* brs, int brsT, TnDefer* defer) {
     const int tiles = (Ka / 128) * (Nb / 128);
     // workgroups: one per CU for up to 8 tiles (same kernel time as two per CU, half the slab bytes: the slab sums go
     // 9.6 -> 7.3 us), two per CU for 12+ tiles (N = 768: 61 vs 72 us); g_tn_blocks != 0 overrides (tools/tn_ablate.py)
@@ -1559,12 +1599,40 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
     int splits = (M + rps - 1) / rps;
     while (want > 8 && (splits & 7) != 0 && rps > TR_ROWS) { rps -= TR_ROWS; splits = (M + rps - 1) / rps; if (splits > 512) break; }
     if (splits > 512) { rps = ((M + want - 1) / want + TR_ROWS - 1) / TR_ROWS * TR_ROWS; splits = (M + rps - 1) / rps; }
+    if (defer && g_tn_phase == 0 && !g_dbg_tn) {
+        // deferred sums: this launch writes the slab buffer whose turn it is, and carries the sums of the previous launch's slabs
+        slab = defer->slab[defer->turn];
+        float* bias_slab2 = dbias ? slab + (size_t)Ka * Nb : nullptr;
+        TnRed prev = {};
+        const int nmain = tiles * splits;
+        int riders = 0;
+        if (defer->pending) {
+            prev = TnRed{defer->p_slab, defer->p_out0, defer->p_out1, defer->p_n0, defer->p_n, defer->p_splits, defer->p_stride, defer->p_nb, defer->p_nbv, nmain};
+            riders = min(128, (defer->p_n + 127) / 128);
+        }
+        const dim3 grid(nmain + riders);
+        if (brs && bias_slab2) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, true>), grid, dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab2, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, prev);
+        else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false>), grid, dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab2, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, prev);
+        const size_t stride = (size_t)Ka * Nb + Nb;
+        const int n0 = ka_valid * Nb, n1 = dbias ? Nb : 0;
+        if (!reduce_cols_ok(slab, out, dbias, n0, n0 + n1, stride) || splits > 64) {        // shapes the rider layout does not take: sum now
+            launch_reduce_slabs2(slab, out, n0, dbias, n1, splits, stride, s, nb_valid ? Nb : 0, nb_valid);
+            defer->pending = false;
+        } else {
+            defer->pending = true;
+            defer->p_slab = slab; defer->p_out0 = out; defer->p_out1 = dbias; defer->p_n0 = n0; defer->p_n = n0 + n1; defer->p_splits = splits; defer->p_stride = stride;
+            defer->p_nb = nb_valid ? Nb : 0; defer->p_nbv = nb_valid;
+        }
+        defer->turn ^= 1;
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     float* bias_slab = dbias ? slab + (size_t)Ka * Nb : nullptr;        // bias partials sit right behind each split's weight partial
+    const TnRed noprev = {};
     if (g_tn_phase != 2)
     {
-        if (g_dbg_tn) hipLaunchKernelGGL((gemm_tn_tr_kernel<1, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn, brs, brsT);
-        else if (brs && bias_slab) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, true>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT);
-        else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT);
+        if (g_dbg_tn) hipLaunchKernelGGL((gemm_tn_tr_kernel<1, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn, brs, brsT, noprev);
+        else if (brs && bias_slab) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, true>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, noprev);
+        else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, noprev);
     }
     if (g_tn_phase != 1)
         launch_reduce_slabs2(slab, out, ka_valid * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s, nb_valid ? Nb : 0, nb_valid);   // rows >= ka_valid of A / columns >= nb_valid of B are zero padding
@@ -1590,13 +1658,22 @@ static int run_tn(int opA, int opB, const void* A, const void* B, float* out, fl
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// sums whatever slabs a deferring caller still has pending (end of the backward pass, or before the gradient is read)
+int launch_gemm_tn_flush(TnDefer* defer, hipStream_t s) {
+    if (defer && defer->pending) {
+        launch_reduce_slabs2(defer->p_slab, defer->p_out0, defer->p_n0, defer->p_out1, defer->p_n - defer->p_n0, defer->p_splits, defer->p_stride, s, defer->p_nb, defer->p_nbv);
+        defer->pending = false;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 bool gemm_tn_bias_rowscale_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, int T) {
     return dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && M % 64 == 0 && Ka % 128 == 0 && Nb % 128 == 0 && M >= 256 && !g_force_tn_regstage && T > 0 && T % 32 == 0;
 }
 
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
-                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid, int nb_valid, const float* bias_rowscale, int bias_T) {
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid, int nb_valid, const float* bias_rowscale, int bias_T, TnDefer* defer) {
     if (M <= 0 || Ka <= 0 || Nb <= 0) { ishara_set_error("gemm_tn: bad shape"); return -1; }
     if (bias_rowscale && !gemm_tn_bias_rowscale_ok(dtA, dtB, dtM, M, Ka, Nb, bias_T)) { ishara_set_error("gemm_tn: bias row scale needs the transposed-read kernel and T %% 32 == 0"); return -1; }
     if (ka_valid <= 0) ka_valid = Ka;
@@ -1611,7 +1688,7 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
         M >= 256 && !g_force_tn_regstage)
     {
         if (ka_valid < Ka && dbias) { ishara_set_error("gemm_tn: padded A columns with a bias gradient"); return -1; }
-        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid, nb_valid, bias_rowscale, bias_T);
+        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid, nb_valid, bias_rowscale, bias_T, defer);
     }
     if (ka_valid != Ka || nb_valid) { ishara_set_error("gemm_tn: padded A columns need the bf16 transposed-read kernel (M %% 64, Ka %% 128, Nb %% 128)"); return -1; }
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<bf16, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);

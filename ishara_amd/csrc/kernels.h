@@ -61,10 +61,16 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
 // gemm_tn_slab_floats(...) floats.
 size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM);
 bool gemm_tn_bias_rowscale_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, int T);   // the transposed-read kernel takes the call and T % 32 == 0
+// Deferred slab sums of the transposed-read wgrad kernel: with a TnDefer the launch writes slab[turn] (two caller-owned buffers of
+// gemm_tn_slab_floats floats each) and the sums of ITS slabs are carried by the next deferring launch as extra workgroups;
+// launch_gemm_tn_flush sums what is still pending.  Launches that take another kernel ignore it (their sums run at once on `slab`).
+struct TnDefer { float* slab[2] = {nullptr, nullptr}; int turn = 0; bool pending = false;
+                 const float* p_slab = nullptr; float* p_out0 = nullptr; float* p_out1 = nullptr; int p_n0 = 0, p_n = 0, p_splits = 0; size_t p_stride = 0; int p_nb = 0, p_nbv = 0; };
+int launch_gemm_tn_flush(TnDefer* defer, hipStream_t s);
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
                    const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0, int nb_valid = 0,
-                   const float* bias_rowscale = nullptr, int bias_T = 0);   // bias_rowscale: dbias = sum_m bias_rowscale[m / bias_T] * B[m,:] (gemm_tn_bias_rowscale_ok shapes only); ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
+                   const float* bias_rowscale = nullptr, int bias_T = 0, TnDefer* defer = nullptr);   // bias_rowscale: dbias = sum_m bias_rowscale[m / bias_T] * B[m,:] (gemm_tn_bias_rowscale_ok shapes only); ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
 // xb[M, Kp] (bf16) = x[M, F] (f32), zero padded to Kp columns (F % 4 == 0, Kp % 8 == 0)
 int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s);
 

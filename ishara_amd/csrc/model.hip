@@ -285,6 +285,9 @@ static void plan_workspace(ishara_model* m) {
     if (dwconv_bwd_scratch_floats(2 * maxw, 31) > slabf) slabf = dwconv_bwd_scratch_floats(2 * maxw, 31);
     if (dwconv_fwd_scratch_floats(B, T, 2 * maxw) > slabf) slabf = dwconv_fwd_scratch_floats(B, T, 2 * maxw);
     m->slab = m->f32(slabf);
+    { size_t wf = 0; for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > wf) wf = f; }
+      if (m->stem_kp) { const size_t f = gemm_tn_slab_floats((int)Mx, m->stem_kp, d, m->dt); if (f > wf) wf = f; }
+      m->slab2[0] = m->f32(wf); m->slab2[1] = m->f32(wf); m->tn_defer_on = getenv("ISHARA_NO_DEFERRED_SLAB_SUMS") == nullptr; }
     m->ctcws = m->f32(ctc_workspace_floats(B, T, m->L));
     m->dlogits = m->f32(Mx * m->C);
     if (m->cls_pad) m->dlb = m->alloc(Mx * (size_t)m->cls_pad * 2);
@@ -476,6 +479,10 @@ int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop
                const float* bias_rowscale, int bias_T) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
     // the GEMM kernel and the sums of its split-M slabs are profiled under separate keys (the kernel's key is its rocprof name)
+    if (m->tn_defer_on && !m->prof.on) {       // the sums of this GEMM's slabs ride with the next weight-gradient GEMM (gemm.hip, TnDefer)
+        m->tn_defer.slab[0] = m->Wf(m->slab2[0]); m->tn_defer.slab[1] = m->Wf(m->slab2[1]);
+        return launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T, &m->tn_defer);
+    }
     g_tn_phase = 1;
     CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T));
     g_tn_phase = 2;
@@ -484,6 +491,8 @@ int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop
     return 0;
 }
 
+
+int wgrad_flush(ishara_model* m) { return launch_gemm_tn_flush(&m->tn_defer, m->s); }
 
 // LayerNorm as a prologue of the GEMM that consumes it (gemm_as.hip): the wave holds whole rows of K, so the statistics cost two
 // cross-lane adds; the normalised rows go to `xn` (training: the weight-gradient GEMM reads them) and the statistics to mean / rstd.
@@ -847,7 +856,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
             STEP(ffn_bwd(m, cb.ffn1, r, lin, g, gn));
         }
 #undef STEP
-        if (!m->bucket_ev.empty() && m->bucket_after_layer[li] >= 0) HIP_CHECK_RET(hipEventRecord(m->bucket_ev[m->bucket_after_layer[li]], m->s));
+        if (!m->bucket_ev.empty() && m->bucket_after_layer[li] >= 0) { CK(wgrad_flush(m)); HIP_CHECK_RET(hipEventRecord(m->bucket_ev[m->bucket_after_layer[li]], m->s)); }
     }
     // ---- stem
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
@@ -858,6 +867,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
         CK(gemm_wgrad(m, wp, m->W(m->stem_xb), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M, m->F));
     } else
         CK(gemm_wgrad(m, m->stemW, m->last_x, DT_F32, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
+    CK(wgrad_flush(m));
     if (!m->bucket_ev.empty()) HIP_CHECK_RET(hipEventRecord(m->bucket_ev.back(), m->s));
     return 0;
 }

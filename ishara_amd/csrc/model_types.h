@@ -120,6 +120,7 @@ struct ishara_model {
     uint32_t nsites = 0;
     std::vector<DenseW*> denses;
     // temps
+    TnDefer tn_defer; Buf slab2[2]; bool tn_defer_on = false;      // deferred wgrad slab sums (gemm.hip): two alternating slab buffers
     Buf gA, gB, t1, t2, t3, S1, S2, E, Fc, Ecol, ecap, dse, dgapT, slab, ctcws, dlogits, nllb, delta;
     size_t shadow_begin = 0, shadow_end = 0;
     size_t shadow_tab_off = 0;             // device descriptor table of the batched shadow build, inside the workspace (no
@@ -185,6 +186,7 @@ int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc,
 int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea);
 int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0, int nb_valid = 0,
                const float* bias_rowscale = nullptr, int bias_T = 0);
+int wgrad_flush(ishara_model* m);
 int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x);
 int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn);
 int r5_ffn_fwd(ishara_model* m, R5FFN& f, const Run& r, const void* x);
