@@ -1144,7 +1144,7 @@ int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count,
 // =====================================================================================
 __global__ __launch_bounds__(256) void eca_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ a, const float* __restrict__ bsh,
                                                       const float* __restrict__ w5, float invT, float* __restrict__ gn,
-                                                      float* __restrict__ sg, float* __restrict__ P, float* __restrict__ Q, int C, const float* __restrict__ rs) {
+                                                      float* __restrict__ sg, float* __restrict__ P, float* __restrict__ Q, int C, float* __restrict__ rs, DropSpec dp, int dp_fold) {
     extern __shared__ float sh[];   // [C + 4]
     const int b = blockIdx.x;
     for (int c = threadIdx.x; c < C + 4; c += blockDim.x) {
@@ -1159,15 +1159,22 @@ __global__ __launch_bounds__(256) void eca_fwd_kernel(const float* __restrict__ 
         const float z = w0 * sh[c] + w1 * sh[c + 1] + w2 * sh[c + 2] + w3 * sh[c + 3] + w4 * sh[c + 4];
         const float sv = sigmoidf_(z);
         sg[(size_t)b * C + c] = sv;
-        const float r = rs ? rs[b] : 1.f;
+        // drop-path scale of this sample (c5:82-83, noise_shape (None,1,1)): drawn here (dp.thr != 0), published in rs[b] for the GEMM
+        // epilogues and the backward pass, and folded into P, Q when `rs` is given
+        float r = 1.f;
+        if (rs) {
+            r = (dp.thr == 0u || rng_keep(rng_row_key(dp.key, (uint32_t)b), 0u, dp.thr)) ? dp.scale : 0.f;
+            if (c == 0) rs[b] = r;
+            if (!dp_fold) r = 1.f;
+        }
         P[(size_t)b * C + c] = a[c] * sv * r;
         Q[(size_t)b * C + c] = bsh[c] * sv * r;
     }
 }
 
 int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
-                   float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, const float* rs) {
-    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, gap, a, b, w5, invT, gn, sgate, P, Q, C, rs);
+                   float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, float* rs, DropSpec dp, int dp_fold) {
+    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, gap, a, b, w5, invT, gn, sgate, P, Q, C, rs, dp, dp_fold);
     return LAUNCH_OK();
 }
 

@@ -128,7 +128,8 @@ int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count,
                                                                                                                        // entering moving_var (torch: n/(n-1))
 // ECA fwd on [B,C]: g = a*gap/T + b ; s = sigmoid(conv5(g)) ; P = a*s ; Q = b*s
 int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
-                   float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, const float* rs = nullptr);   // rs: P, Q additionally scaled by rs[b] (drop-path folded into the affine)
+                   float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, float* rs = nullptr, DropSpec dp = {0, 0, 1.f}, int dp_fold = 0);
+// rs != nullptr: the kernel also draws the per-sample drop-path scale rs[b] (dp) and, with dp_fold, scales P and Q by it
 // y = x*P[b,c] + Q[b,c] (+ resid)    (P,Q per sample) ; if Q == nullptr -> no offset
 int launch_sample_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y,
                          int B, int T, int C, hipStream_t s);

@@ -529,15 +529,14 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
     EpiArgs e2; e2.resid = x;
     cb.folded = false;
-    if (ds.thr) {
-        hipLaunchKernelGGL(droppath_kernel, dim3((B + 255) / 256), dim3(256), 0, m->s, m->Wf(cb.rs), B, ds);
+    if (ds.thr) {                                        // rs[b] itself is drawn by eca_fwd below (one launch less per block)
         e2.rowscale = m->Wf(cb.rs); e2.T = T;
         EpiArgs probe = e2; probe.bias = m->P(cb.W2.b);
         cb.folded = dt == DT_BF16 && !g_force_regstage && gemm_nt_as_applicable(dt, r.M, cb.W2.N, cb.W2.K, cb.W2.ldt, probe) && gemm_nt_as_applicable(dt, r.M, cb.W2.K, cb.W2.N, cb.W2.ldn, probe) &&
                     gemm_tn_bias_rowscale_ok(dt, dt, dt, r.M, cb.W2.K, cb.W2.N, T);
         e2.rowscale_bias = cb.folded ? 1 : 0;
     }
-    CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s, cb.folded ? m->Wf(cb.rs) : nullptr));
+    CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s, ds.thr ? m->Wf(cb.rs) : nullptr, ds, cb.folded ? 1 : 0));
     // h4 = h2 * P[b] + Q[b] (BatchNorm + ECA gate [+ drop-path]) as a prologue of the project GEMM: h2 is read once, h4 is written from
     // the transformed fragments for the weight-gradient GEMM (training only); other shapes run the separate affine pass
     {
