@@ -1243,16 +1243,57 @@ int launch_col_affine(int dt, const void* x, const float* a, const float* b, voi
 // BatchNorm backward pieces
 // =====================================================================================
 // Conv1DBlock (BN -> ECA): step 1, per sample.  E <- dgn[b,c]; dw5 += sum dz*gn(shifted)
-__global__ __launch_bounds__(256) void eca_bwd_sample_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+// ps.G != nullptr (PsaStats, kernels.h): S1, S2 of this sample are first computed from what the per-sample-affine weight-gradient GEMM
+// emitted — S1[c] = rs * sum_n Wt[n,c] G[n], S2[c] = rstd[c] * (rs * sum_p Rpart[p][c] - mean[c] * S1[c]) — by the same workgroup: thread
+// (cg, w) takes 8 channels (16-byte weight loads, channel = fast index) and a quarter of the N weight rows, 32 loads in flight (one thread
+// per channel over all N sat on load latency: 37 us as a kernel of its own)
+__global__ __launch_bounds__(256) void eca_bwd_sample_kernel(float* __restrict__ S1, float* __restrict__ S2,
                                                              const float* __restrict__ gn, const float* __restrict__ sg,
                                                              const float* __restrict__ w5, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ E,
-                                                             float* __restrict__ dw5part, int C) {
-    extern __shared__ float sh[];   // dz[C+4], g[C+4]
+                                                             float* __restrict__ dw5part, int C, PsaStats ps) {
+    extern __shared__ float sh[];   // dz[C+4], g[C+4]  (PsaStats: first G[N] | partial sums [4][C])
     float* dz = sh;
     float* g = sh + C + 4;
     __shared__ float wred[5][4];
     const int b = blockIdx.x;
+    if (ps.G) {
+        const int N = ps.N, cg = threadIdx.x & 63, w = threadIdx.x >> 6;
+        float* gl = sh;                 // [N]
+        float* part = sh + N;           // [4][C]
+        for (int n = threadIdx.x; n < N; n += 256) gl[n] = ps.G[(size_t)b * N + n];
+        const bf16* Wt = reinterpret_cast<const bf16*>(ps.Wt);
+        const int nq = (N + 3) / 4, nbeg = w * nq, nend = min(N, nbeg + nq);
+        __syncthreads();
+        for (int c0 = cg * 8; c0 < C; c0 += 512) {
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = 0.f;
+            for (int n = nbeg; n < nend; n += 32) {
+                bf16x8 wv[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) wv[u] = *reinterpret_cast<const bf16x8*>(Wt + (size_t)min(n + u, nend - 1) * ps.ldt + c0);
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const float gv = n + u < nend ? gl[n + u] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] += (float)wv[u][e] * gv;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[w * C + c0 + e] = a[e];
+        }
+        __syncthreads();
+        const float r = ps.rs ? ps.rs[b] : 1.f;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float R = 0.f;
+            for (int p = 0; p < ps.nparts; ++p) R += ps.Rpart[((size_t)b * ps.nparts + p) * C + c];
+            const float s1 = r * (part[c] + part[C + c] + part[2 * C + c] + part[3 * C + c]);
+            S1[(size_t)b * C + c] = s1;
+            S2[(size_t)b * C + c] = ps.rstd[c] * (r * R - ps.mean[c] * s1);
+        }
+        __syncthreads();                // S1, S2 of this sample are visible to the workgroup; sh is free again
+    }
     for (int c = threadIdx.x; c < C + 4; c += blockDim.x) {
         const int cc = c - 2;
         float z = 0.f, gg = 0.f;
@@ -1329,10 +1370,14 @@ __global__ __launch_bounds__(1024) void eca_bn_bwd_channel_kernel(const float* _
     }
 }
 
-int launch_eca_bn_bwd_finalize(const float* S1, const float* S2, const float* gap, const float* gn, const float* sgate,
+int launch_eca_bn_bwd_finalize(float* S1, float* S2, const float* gap, const float* gn, const float* sgate,
                                const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part, int B, int T, int C, hipStream_t s) {
-    hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B), dim3(256), 2 * (C + 4) * sizeof(float), s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5part, C);
+                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part, int B, int T, int C, hipStream_t s, const PsaStats* ps) {
+    PsaStats p = ps ? *ps : PsaStats{};
+    if (p.G && (C % 8 != 0 || p.ldt % 8 != 0 || ((uintptr_t)p.Wt) % 16 != 0)) { ishara_set_error("eca_bn_bwd_finalize: PsaStats needs C %% 8 == 0 and 16-byte aligned weight rows"); return -1; }
+    size_t shm = 2 * (C + 4) * sizeof(float);
+    if (p.G && (size_t)(p.N + 4 * C) * sizeof(float) > shm) shm = (size_t)(p.N + 4 * C) * sizeof(float);
+    hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B), dim3(256), shm, s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5part, C, p);
     hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, dw5part, dw5, B, T, C);
     return LAUNCH_OK();
 }

@@ -1228,7 +1228,7 @@ DEVI void tr_wait(TrFrags& f) {
 
 // The slab sums of the PREVIOUS weight-gradient GEMM ride along as extra workgroups of the next one (blockIdx.x >= nmain): the sums are
 // ~5 us kernels that leave the chip idle, 59 of them per step; here they run beside the GEMM's workgroups (two slab buffers alternate).
-struct TnRed { const float* slab; float* out0; float* out1; int n0, n, splits; size_t stride; int nb, nbv, nmain; };
+struct TnRed { const float* slab; float* out0; float* out1; int n0, n, splits; size_t stride; int nb, nbv, nmain; int inl; };   // inl: no rider workgroups — every main workgroup sums its share after its tile (PSA: one workgroup per CU, riders could not run beside them)
 DEVI void tn_reduce_block(const TnRed& r, int rb, int nrb, float4 (*red)[32]) {
     constexpr int SL = 8, CQ = 32;                       // the layout of reduce_slabs_cols_kernel<8, 32>
     const int tid = threadIdx.x, cq = tid % CQ, sl = tid / CQ;
@@ -1262,17 +1262,100 @@ DEVI void tn_reduce_block(const TnRed& r, int rb, int nrb, float4 (*red)[32]) {
     }
 }
 
-template <int DBG, bool BRS = false>      // DBG = 1: the ablation bits of tools/gemm_ablate.py are honoured (kept out of the production loop); BRS: weighted bias sum
-__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+template <int CTRL> DEVI float tn_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// One sample of the split is complete (PSA).  Its accumulator is folded into the running total with the sample's affine, and the
+// statistics of the gradient of the transformed operand are emitted — but not on the spot: a pause of the whole workgroup (~700 VALU
+// instructions per wave) lets the 3-stage operand ring run dry, and refilling it cost more than the arithmetic (first version: 4 us per
+// boundary, 77 us per launch against 41 without).  tn_psa_begin parks the finished accumulator (hold) and the sample's column sums; the
+// four 16-row chunks are processed by tn_psa_chunk<I> in the next four steps, in the same basic block as their MFMAs (samples are a
+// multiple of four stages long, so chunk I always sits in step copy I of the 4x unrolled loop).  Two accumulator sets alternating between
+// samples (no parking) made hipcc spill 250 registers per lane to scratch.  The statistics go to LDS (po: this lane's R quad of the
+// sample's 384-float record [4 waves x 64 R | 128 G], asm stores: a builtin LDS access would wait for all operand DMA) and to memory
+// after the loop — global stores in the loop would sit in vmcnt between the DMAs and be waited for by the steps' vmcnt(8).
+DEVI void tn_psa_begin(f32x4 (&acc)[4][4], f32x4 (&hold)[4][4], f32x4 (&gacc)[4], float (&ctot)[4], float (&gbh)[4], unsigned gaddr,
+                       bool psa_g, const float* __restrict__ brs, int sample, int lane, u32x4 z8) {
+    // column sums of B over the sample's rows: an MFMA with an all-ones A operand per B fragment (every accumulator row holds them — no
+    // cross-lane fold; summing the unpacked fragments on the VALU in every wave cost 10 us per launch)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gbh[j] = gacc[j][0]; gacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (psa_g) {
+        const float sc = brs ? brs[sample] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ctot[j] += sc * gbh[j];
+        if ((lane >> 4) == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("ds_write_b32 %0, %1" :: "v"(gaddr + 64u * j), "v"(gbh[j]) : "memory");
+        }
+    }
+    // park the finished accumulator and clear it ON THE MATRIX PIPE (z8 = an all-zero operand the compiler cannot see through):
+    // hold = 0 x 0 + acc, acc = 0 x 0 + 0 — 32 MFMAs the pipe has room for, instead of ~200 accumulator-register moves on the VALU
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hold[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, z8), __builtin_bit_cast(bf16x8, z8), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, z8), __builtin_bit_cast(bf16x8, z8), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+}
+// The running total lives in LDS (tot_lds: this lane's 16-byte slot of the wave's [16 tiles][64 lanes] f32x4 block): with it in registers
+// the kernel needed 530 of the 512 registers a wave can have.
+template <int I>
+DEVI void tn_psa_chunk(const f32x4 (&hold)[4][4], unsigned tot_lds, const tn_u32x2 (&wv)[4][4], const float (&gbh)[4], unsigned prow, unsigned orow, int lane) {
+    f32x4 p4, q4, tot[1][4];
+    asm volatile("ds_read_b128 %0, %1" : "=v"(p4) : "v"(prow + 64u * I));
+    asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(q4) : "v"(prow + 64u * I));
+    const unsigned ta = tot_lds + 4096u * I;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(tot[0][0]) : "v"(ta));
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(tot[0][1]) : "v"(ta));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(tot[0][2]) : "v"(ta));
+    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(tot[0][3]) : "v"(ta));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p4), "+v"(q4), "+v"(tot[0][0]), "+v"(tot[0][1]), "+v"(tot[0][2]), "+v"(tot[0][3]));
+    f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float w0 = __uint_as_float(wv[I][j].x << 16), w1 = __uint_as_float(wv[I][j].x & 0xffff0000u);
+        const float w2 = __uint_as_float(wv[I][j].y << 16), w3 = __uint_as_float(wv[I][j].y & 0xffff0000u);
+        const f32x4 a = hold[I][j];
+        const f32x4 w4 = {w0, w1, w2, w3};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            tot[0][j][r] += p4[r] * a[r] + q4[r] * gbh[j];
+            rr[r] += w4[r] * a[r];
+        }
+    }
+    asm volatile("ds_write_b128 %0, %1" :: "v"(ta), "v"(tot[0][0]) : "memory");
+    asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(ta), "v"(tot[0][1]) : "memory");
+    asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(ta), "v"(tot[0][2]) : "memory");
+    asm volatile("ds_write_b128 %0, %1 offset:3072" :: "v"(ta), "v"(tot[0][3]) : "memory");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                         // sum over the 16 column lanes of the row (quad swaps, half mirror, mirror)
+        float v = rr[r];
+        v = tn_dpp_add<0xB1>(v); v = tn_dpp_add<0x4E>(v); v = tn_dpp_add<0x141>(v); v = tn_dpp_add<0x140>(v);
+        rr[r] = v;
+    }
+    if ((lane & 15) == 0) asm volatile("ds_write_b128 %0, %1" :: "v"(orow + 64u * I), "v"(rr) : "memory");
+}
+
+#define TN_PSA_MAXS 8          // samples per M-split the per-sample-affine variant stages coefficients for
+// DBG = 1: the ablation bits of tools/gemm_ablate.py are honoured (kept out of the production loop); BRS: weighted bias sum;
+// PSA: per-sample affine of the A operand + the BatchNorm / ECA backward statistics (TnPsa, kernels.h): one workgroup per CU (the per-sample
+// accumulator, the running total and the weight tile take 192 registers)
+template <int DBG, bool BRS = false, bool PSA = false>
+__global__ __launch_bounds__(256, PSA ? 1 : 2) void gemm_tn_tr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                          float* __restrict__ out, float* __restrict__ dbias,
                                                          int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, int dbg,
-                                                         const float* __restrict__ brs, int brsT, TnRed prev) {
+                                                         const float* __restrict__ brs, int brsT, TnRed prev, TnPsa psa) {
     // brs != nullptr: the bias gradient is the column sum of brs[m / brsT] * B[m,:] (drop-path scale of the sample a row belongs to;
     // brsT % 32 == 0, so the 32 rows of a stage share it)
     // slab layout: [split][Ka*Nb weight partial | Nb bias partial] so that ONE reduction launch sums both
     const size_t sstride = (size_t)Ka * Nb + Nb;
     __shared__ __attribute__((aligned(16))) char smem[TR_NSTAGE * TR_STAGE];
-    if (prev.nmain > 0 && (int)blockIdx.x >= prev.nmain) {        // a rider: sums a slice of the previous launch's slabs
+    __shared__ __attribute__((aligned(16))) float pq_tab[PSA ? TN_PSA_MAXS * 256 : 4];     // [sample of this split][P of the tile's 128 rows | Q]
+    __shared__ __attribute__((aligned(16))) float psa_out[PSA ? TN_PSA_MAXS * 384 : 4];    // [sample of this split][R: 4 waves x 64 rows | G: 128 columns]
+    __shared__ __attribute__((aligned(16))) f32x4 tot_tab[PSA ? 4 * 16 * 64 : 1];          // [wave][tile i*4+j][lane]: the running total (sum over finished samples)
+    if (prev.nmain > 0 && !prev.inl && (int)blockIdx.x >= prev.nmain) {        // a rider: sums a slice of the previous launch's slabs
         tn_reduce_block(prev, (int)blockIdx.x - prev.nmain, (int)gridDim.x - prev.nmain, reinterpret_cast<float4 (*)[32]>(smem));
         return;
     }
@@ -1295,19 +1378,59 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
     const int nmc = max(0, m_end - m_beg) / TR_ROWS;      // whole 32-row tiles (launcher guarantees)
     const bool want_bias = (dbias != nullptr) && (kt == 0) && (wr == 0);
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][4], hold[4][4];           // hold (PSA): the previous sample's accumulator while its chunks are processed
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; hold[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     // weighted bias sum: csum collects the rows of the current sample; at a sample boundary (every brsT / 32 stages) it is folded into
     // ctot with that sample's scale — one scalar load per sample instead of one per stage (a scalar load in the step loop shares
     // lgkmcnt with the fragment reads and stalls them)
     float ctot[4] = {0.f, 0.f, 0.f, 0.f};
-    const int seg_stages = BRS ? brsT / TR_ROWS : 0;
-    int seg_left = BRS ? seg_stages - (m_beg % brsT) / TR_ROWS : -1;
-    int seg_sample = BRS ? m_beg / brsT : 0;
+    const int seg_stages = PSA ? psa.T / TR_ROWS : (BRS ? brsT / TR_ROWS : 0);
+    const int seg_iters = seg_stages / 4;                    // PSA: samples are a multiple of 4 stages (launcher)
+    int seg_left = PSA ? seg_iters : (BRS ? seg_stages - (m_beg % brsT) / TR_ROWS : -1);      // PSA: splits are whole samples (launcher)
+    int seg_sample = PSA ? m_beg / psa.T : (BRS ? m_beg / brsT : 0);
+    // ---- PSA state: tot = sum over finished samples of P[b] * acc_b + Q[b] x colsum_b ; wv = this wave's 64x64 block of W in the
+    // accumulator layout (row 16i + 4(lane>>4) + r, column 16j + (lane&15))
+    tn_u32x2 wv[4][4];                                       // bf16 pairs (rows r0|r1, r2|r3)
+    float gbh[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gacc[4];                                           // column sums of the current sample's B rows (ones x B fragments)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones8 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    bool first = false;                                      // the running iteration is the first of a sample whose predecessor is parked
+    u32x4 z8 = {0u, 0u, 0u, 0u};                             // an all-zero MFMA operand, opaque to the compiler (tn_psa_begin)
+    asm volatile("" : "+v"(z8));
+    unsigned pq_hold = 0, po_hold = 0;
+    unsigned pq_row = (unsigned)(uintptr_t)pq_tab + 4u * (wr * 64 + 4 * (lane >> 4));     // LDS byte address of this lane's coefficient quad
+    unsigned po_row = (unsigned)(uintptr_t)psa_out + 4u * (wid * 64 + 4 * (lane >> 4));    // ... of its R quad, and of its G column
+    unsigned po_g = (unsigned)(uintptr_t)psa_out + 4u * (256 + wc * 64 + (lane & 15));
+    const unsigned tot_lds = (unsigned)(uintptr_t)tot_tab + 16u * (wid * 16 * 64 + lane);
+    const bool psa_g = PSA && kt == 0 && wr == 0;            // the waves that publish G[b, :] and own the bias sum
+    float tv[PSA ? TN_PSA_MAXS : 1];
+    if constexpr (PSA) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tot_tab[(wid * 16 + i * 4 + j) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ns = nmc / seg_stages;
+        const float* src = (tid < 128 ? psa.P : psa.Q) + (size_t)seg_sample * Ka + k0 + (tid & 127);
+#pragma unroll
+        for (int sidx = 0; sidx < TN_PSA_MAXS; ++sidx) tv[sidx] = (sidx < ns && !(psa.dbg & 4)) ? src[(size_t)sidx * Ka] : 0.f;
+        const bf16* wsrc = reinterpret_cast<const bf16*>(psa.W) + (size_t)(k0 + wr * 64 + 4 * (lane >> 4)) * psa.ldw + n0 + wc * 64 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned short* wp = reinterpret_cast<const unsigned short*>(wsrc) + (size_t)(16 * i) * psa.ldw + 16 * j;
+                if (psa.dbg & 4) { wv[i][j].x = 0u; wv[i][j].y = 0u; continue; }
+                wv[i][j].x = (unsigned)wp[0] | ((unsigned)wp[psa.ldw] << 16);
+                wv[i][j].y = (unsigned)wp[2 * (size_t)psa.ldw] | ((unsigned)wp[3 * (size_t)psa.ldw] << 16);
+            }
+    }
+    (void)psa_out; (void)tv;
 
     // Software pipeline over the 32-row stages (ring of 4 x 16 KB, slots addressed statically: the loop is unrolled by 4):
     // at step mc the MFMAs of stage mc run from fragments already in registers while the transposing LDS reads of stage
@@ -1361,7 +1484,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         }                                                                                                                \
     }
 #define TN_COMPUTE(CUR)                                                                                                  \
-    if (want_bias) {                                                                                                     \
+    if (PSA) {                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
+            gacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones8), __builtin_bit_cast(bf16x8, CUR.b[j]), gacc[j], 0, 0, 0); \
+    }                                                                                                                    \
+    if (!PSA && want_bias) {                                                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
             float t = 0.f;                                                                                               \
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                \
@@ -1377,7 +1504,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i][0][0] += __uint_as_float(CUR.a[i][0]) + __uint_as_float(CUR.b[i][0]); \
     }
     // one step: FULL = at least two younger stages are in flight behind stage mc+U+1 (steady state: no branches)
-#define TN_STEP(U, CUR, NXT, FULL)                                                                                       \
+#define TN_STEP(U, CUR, NXT, FULL, CH)                                                                                   \
     if (FULL || mc + (U) < nmc_run) {                                                                                    \
         if (FULL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                       \
         else {                                                                                                           \
@@ -1390,15 +1517,38 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         TN_ISSUE(U, mc + (U) + TR_NSTAGE)                                                                                \
         if ((FULL || mc + (U) + 1 < nmc_run) && !no_frag) tr_read_asm<((U) + 1) & 3>(fa, fb, NXT);                       \
         TN_COMPUTE(CUR)                                                                                                  \
-        if (BRS && want_bias && --seg_left == 0) {                                                                       \
+        if (PSA && first) tn_psa_chunk<(U)>(hold, tot_lds, wv, gbh, pq_hold, po_hold, lane);     /* behind the MFMAs' issue */   \
+        if (!PSA && BRS && want_bias && --seg_left == 0) {                                                               \
             const float sc = brs[seg_sample];                                                                            \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) { ctot[j] += sc * csum[j]; csum[j] = 0.f; }                    \
             seg_left = seg_stages; ++seg_sample;                                                                         \
-        }                                                                                                  \
+        }                                                                                                                \
+        if (PSA) {                                                                                                       \
+            if ((U) == 3) {                                                                                              \
+                first = false;                                                                                           \
+                if (--seg_left == 0 && !(psa.dbg & 1)) {                                                                 \
+                    tn_psa_begin(acc, hold, gacc, ctot, gbh, po_g, psa_g, brs, seg_sample, lane, z8);                    \
+                    first = true; pq_hold = pq_row; po_hold = po_row;                                                    \
+                    pq_row += 1024u; po_row += 1536u; po_g += 1536u; seg_left = seg_iters; ++seg_sample;                 \
+                }                                                                                                        \
+            }                                                                                                            \
+        }                                                                                                                \
         tr_wait(NXT);                                                                                                    \
     }
 
     TN_ISSUE(0, 0) TN_ISSUE(1, 1) TN_ISSUE(2, 2) TN_ISSUE(3, 3)
+    if constexpr (PSA) {
+        // the coefficient / weight loads were issued before the first four stages' DMA and complete before it (loads return in order); the
+        // values are pinned here — passing them through an empty asm keeps hipcc from putting their wait at the first use inside the
+        // pipelined loop, where a vmcnt(0) would drain the operand DMA at every sample boundary
+#pragma unroll
+        for (int sidx = 0; sidx < TN_PSA_MAXS; ++sidx) pq_tab[sidx * 256 + tid] = tv[sidx];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(wv[i][j]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     int mc = 0;
     if (nmc_run > 0) {
         // stage 0 landed: its 4 DMA are the oldest of up to 16
@@ -1407,20 +1557,40 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         __builtin_amdgcn_s_barrier();
         if (!no_frag) tr_read_asm<0>(fa, fb, P);
         tr_wait(P);
+#define TN_ITER(FULL, CH) TN_STEP(0, P, Q, FULL, CH) TN_STEP(1, Q, P, FULL, CH) TN_STEP(2, P, Q, FULL, CH) TN_STEP(3, Q, P, FULL, CH)
+#define TN_CHUNKS tn_psa_chunk<0>(hold, tot_lds, wv, gbh, pq_hold, po_hold, lane); tn_psa_chunk<1>(hold, tot_lds, wv, gbh, pq_hold, po_hold, lane); \
+                  tn_psa_chunk<2>(hold, tot_lds, wv, gbh, pq_hold, po_hold, lane); tn_psa_chunk<3>(hold, tot_lds, wv, gbh, pq_hold, po_hold, lane);
         for (; mc + 7 <= nmc_run; mc += 4) {          // steps mc .. mc+3 all have stages mc+U+3 <= nmc-1 behind them
-            TN_STEP(0, P, Q, true) TN_STEP(1, Q, P, true) TN_STEP(2, P, Q, true) TN_STEP(3, Q, P, true)
+            TN_ITER(true, false)                      // PSA: the four chunks of a parked sample ride in the sample's first four steps (a second
+                                                      // copy of the loop body with unconditional chunks made hipcc spill 160 registers)
         }
         for (; mc < nmc_run; mc += 4) {
-            TN_STEP(0, P, Q, false) TN_STEP(1, Q, P, false) TN_STEP(2, P, Q, false) TN_STEP(3, Q, P, false)
+            TN_ITER(false, false)
         }
     }
+#undef TN_ITER
 #undef TN_STEP
 #undef TN_COMPUTE
 #undef TN_ISSUE
+    if constexpr (PSA) {
+        if (first) { TN_CHUNKS }          // the split's last sample was parked by the final step
+    }
+#undef TN_CHUNKS
 
     // ---- write this split's 128x128 partial to its fp32 slab: each wave transposes its 64x64 accumulator block through
     // a private LDS stage (two 32-row passes) so that every store instruction writes 4 rows x 256 contiguous bytes
     __syncthreads();                       // the ring is free
+    if constexpr (PSA) {                   // the samples' statistics: LDS -> Rpart / G
+        const int ns = nmc / seg_stages, b0 = m_beg / psa.T;
+        for (int idx = tid; idx < ns * 384 && !(psa.dbg & 16); idx += 256) {
+            const int sl = idx / 384, e = idx - sl * 384;
+            const float v = psa_out[idx];
+            if (e < 256) {
+                const int w_ = e >> 6, row = e & 63;
+                psa.Rpart[((size_t)(b0 + sl) * (Nb >> 6) + nt * 2 + (w_ & 1)) * Ka + k0 + (w_ >> 1) * 64 + row] = v;
+            } else if (kt == 0) psa.G[(size_t)(b0 + sl) * Nb + n0 + (e - 256)] = v;
+        }
+    }
     if (DBG != 0 && (dbg & 8) != 0) { if (acc[0][0][0] == 123.f) out[0] = acc[1][1][1]; return; }
     {
         constexpr int SLD = 68;
@@ -1433,7 +1603,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        stage[(16 * ii + 4 * (lane >> 4) + r) * SLD + 16 * j + (lane & 15)] = acc[2 * p + ii][j][r];
+                        stage[(16 * ii + 4 * (lane >> 4) + r) * SLD + 16 * j + (lane & 15)] = PSA ? tot_tab[(wid * 16 + (2 * p + ii) * 4 + j) * 64 + lane][r] : acc[2 * p + ii][j][r];
             float* orow = out + (size_t)split * sstride + (size_t)(k0 + wr * 64 + 32 * p + (lane >> 4)) * Nb + n0 + wc * 64 + (lane & 15) * 4;
 #pragma unroll
             for (int it = 0; it < 8; ++it)       // one instruction = 4 rows x 256 contiguous bytes
@@ -1441,7 +1611,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
         }
     }
     if (want_bias) {   // lane (g, c) holds the sum over rows 8g..8g+7 (mod 32) of column 16j + c: fold the 4 row groups
-        if (BRS) {      // the rows of the last, unfinished sample of this split
+        if (PSA) {      // every sample of the split was folded at its boundary; all four row groups hold the full sums
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csum[j] = (lane >> 4) == 0 ? ctot[j] : 0.f;
+        } else if (BRS) {      // the rows of the last, unfinished sample of this split
             const float sc = seg_left != seg_stages && seg_sample * brsT < M ? brs[seg_sample] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) csum[j] = ctot[j] + sc * csum[j];
@@ -1453,6 +1626,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16* __restri
             t += __shfl_xor(t, 32, 64);
             if (lane < 16) dbias[(size_t)split * sstride + n0 + wc * 64 + 16 * j + lane] = t;
         }
+    }
+    if (PSA && prev.nmain > 0 && prev.inl) {        // the previous launch's slab sums, a share per workgroup
+        __syncthreads();
+        tn_reduce_block(prev, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<float4 (*)[32]>(smem));
     }
 }
 
@@ -1585,9 +1762,31 @@ int g_force_tn_regstage = 0;   // tests: force the register-transposing TN kerne
 int g_tn_blocks = 0;
 int g_tn_phase = 0;            // 0: GEMM + slab sums; 1: GEMM kernel only; 2: slab sums only (the model profiles the two separately)
 
+// PSA split plan: whole samples per split (the statistics of a sample come from one workgroup per output tile), at most TN_PSA_MAXS of them,
+// as close to one workgroup per CU as the batch allows; 0 = no such plan
+static int tn_psa_splits(int M, int Ka, int Nb, int T) {
+    if (T <= 0 || T % (4 * TR_ROWS) != 0 || M % T != 0) return 0;      // samples = whole iterations of the 4x unrolled step loop
+    const int Bn = M / T, tiles = (Ka / 128) * (Nb / 128);
+    const int want = max(1, 256 / tiles);
+    for (int d = min(want, Bn); d >= 1; --d) {
+        if (Bn % d != 0) continue;
+        if (d > 8 && (d & 7) != 0) continue;              // keeps the XCD-aware (tile, split) mapping
+        const int ns = Bn / d;
+        if (ns > TN_PSA_MAXS) return 0;
+        if (ns * T < 256) continue;                       // at least 8 stages per split
+        return d;
+    }
+    return 0;
+}
+bool gemm_tn_psa_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, int T) {
+    return dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && M % 64 == 0 && Ka % 128 == 0 && Nb % 128 == 0 && M >= 256 && !g_force_tn_regstage &&
+           !g_dbg_tn && tn_psa_splits(M, Ka, Nb, T) > 0;
+}
+
 static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s, int ka_valid, int nb_valid,
-                     const float* brs, int brsT, TnDefer* defer) {
+                     const float* brs, int brsT, TnDefer* defer, const TnPsa* psa) {
     const int tiles = (Ka / 128) * (Nb / 128);
+    const TnPsa nopsa = {};
     // workgroups: one per CU for up to 8 tiles (same kernel time as two per CU, half the slab bytes: the slab sums go
     // 9.6 -> 7.3 us), two per CU for 12+ tiles (N = 768: 61 vs 72 us); g_tn_blocks != 0 overrides (tools/tn_ablate.py)
     const int blocks = g_tn_blocks ? g_tn_blocks : (tiles <= 8 ? 256 : 512);
@@ -1599,6 +1798,11 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
     int splits = (M + rps - 1) / rps;
     while (want > 8 && (splits & 7) != 0 && rps > TR_ROWS) { rps -= TR_ROWS; splits = (M + rps - 1) / rps; if (splits > 512) break; }
     if (splits > 512) { rps = ((M + want - 1) / want + TR_ROWS - 1) / TR_ROWS * TR_ROWS; splits = (M + rps - 1) / rps; }
+    if (psa) {
+        splits = tn_psa_splits(M, Ka, Nb, psa->T);
+        if (splits <= 0 || g_dbg_tn) { ishara_set_error("gemm_tn: no per-sample-affine plan for M=%d T=%d (gemm_tn_psa_ok)", M, psa->T); return -1; }
+        rps = M / splits;
+    }
     if (defer && g_tn_phase == 0 && !g_dbg_tn) {
         // deferred sums: this launch writes the slab buffer whose turn it is, and carries the sums of the previous launch's slabs
         slab = defer->slab[defer->turn];
@@ -1607,12 +1811,13 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
         const int nmain = tiles * splits;
         int riders = 0;
         if (defer->pending) {
-            prev = TnRed{defer->p_slab, defer->p_out0, defer->p_out1, defer->p_n0, defer->p_n, defer->p_splits, defer->p_stride, defer->p_nb, defer->p_nbv, nmain};
-            riders = min(128, (defer->p_n + 127) / 128);
+            prev = TnRed{defer->p_slab, defer->p_out0, defer->p_out1, defer->p_n0, defer->p_n, defer->p_splits, defer->p_stride, defer->p_nb, defer->p_nbv, nmain, psa ? 1 : 0};
+            riders = psa ? 0 : min(128, (defer->p_n + 127) / 128);
         }
         const dim3 grid(nmain + riders);
-        if (brs && bias_slab2) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, true>), grid, dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab2, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, prev);
-        else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false>), grid, dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab2, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, prev);
+        if (psa) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false, true>), grid, dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab2, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, prev, *psa);
+        else if (brs && bias_slab2) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, true>), grid, dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab2, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, prev, nopsa);
+        else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false>), grid, dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab2, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, prev, nopsa);
         const size_t stride = (size_t)Ka * Nb + Nb;
         const int n0 = ka_valid * Nb, n1 = dbias ? Nb : 0;
         if (!reduce_cols_ok(slab, out, dbias, n0, n0 + n1, stride) || splits > 64) {        // shapes the rider layout does not take: sum now
@@ -1630,9 +1835,10 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
     const TnRed noprev = {};
     if (g_tn_phase != 2)
     {
-        if (g_dbg_tn) hipLaunchKernelGGL((gemm_tn_tr_kernel<1, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn, brs, brsT, noprev);
-        else if (brs && bias_slab) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, true>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, noprev);
-        else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, noprev);
+        if (psa) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false, true>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, noprev, *psa);
+        else if (g_dbg_tn) hipLaunchKernelGGL((gemm_tn_tr_kernel<1, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, g_dbg_tn, brs, brsT, noprev, nopsa);
+        else if (brs && bias_slab) hipLaunchKernelGGL((gemm_tn_tr_kernel<0, true>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, noprev, nopsa);
+        else hipLaunchKernelGGL((gemm_tn_tr_kernel<0, false>), dim3(tiles * splits), dim3(256), 0, s, (const bf16*)A, (const bf16*)B, slab, bias_slab, M, Ka, Nb, rps, tiles, splits, 0, brs, brsT, noprev, nopsa);
     }
     if (g_tn_phase != 1)
         launch_reduce_slabs2(slab, out, ka_valid * Nb, dbias, dbias ? Nb : 0, splits, (size_t)Ka * Nb + Nb, s, nb_valid ? Nb : 0, nb_valid);   // rows >= ka_valid of A / columns >= nb_valid of B are zero padding
@@ -1673,8 +1879,12 @@ bool gemm_tn_bias_rowscale_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, 
 
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
-                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid, int nb_valid, const float* bias_rowscale, int bias_T, TnDefer* defer) {
+                   const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid, int nb_valid, const float* bias_rowscale, int bias_T, TnDefer* defer, const TnPsa* psa) {
     if (M <= 0 || Ka <= 0 || Nb <= 0) { ishara_set_error("gemm_tn: bad shape"); return -1; }
+    if (psa && (!gemm_tn_psa_ok(dtA, dtB, dtM, M, Ka, Nb, psa->T) || opA != OP_NONE || opB != OP_NONE || ka_valid > 0 || nb_valid > 0 || !psa->P || !psa->Q || !psa->W || !psa->G || !psa->Rpart ||
+                (bias_rowscale && bias_T != psa->T))) {
+        ishara_set_error("gemm_tn: per-sample affine needs the transposed-read kernel, whole samples per split and all of P, Q, W, G, Rpart (gemm_tn_psa_ok)"); return -1;
+    }
     if (bias_rowscale && !gemm_tn_bias_rowscale_ok(dtA, dtB, dtM, M, Ka, Nb, bias_T)) { ishara_set_error("gemm_tn: bias row scale needs the transposed-read kernel and T %% 32 == 0"); return -1; }
     if (ka_valid <= 0) ka_valid = Ka;
     if (nb_valid >= Nb || nb_valid < 0) nb_valid = 0;
@@ -1688,7 +1898,7 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
         M >= 256 && !g_force_tn_regstage)
     {
         if (ka_valid < Ka && dbias) { ishara_set_error("gemm_tn: padded A columns with a bias gradient"); return -1; }
-        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid, nb_valid, bias_rowscale, bias_T, defer);
+        return run_tn_tr(A, B, out, dbias, slab, M, Ka, Nb, s, ka_valid, nb_valid, bias_rowscale, bias_T, defer, psa);
     }
     if (ka_valid != Ka || nb_valid) { ishara_set_error("gemm_tn: padded A columns need the bf16 transposed-read kernel (M %% 64, Ka %% 128, Nb %% 128)"); return -1; }
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16) return run_tn<bf16, bf16, bf16>(opA, opB, A, B, out, dbias, slab, M, Ka, Nb, dtM, oa, ob, s);

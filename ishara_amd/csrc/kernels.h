@@ -67,10 +67,21 @@ bool gemm_tn_bias_rowscale_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, 
 struct TnDefer { float* slab[2] = {nullptr, nullptr}; int turn = 0; bool pending = false;
                  const float* p_slab = nullptr; float* p_out0 = nullptr; float* p_out1 = nullptr; int p_n0 = 0, p_n = 0, p_splits = 0; size_t p_stride = 0; int p_nb = 0, p_nbv = 0; };
 int launch_gemm_tn_flush(TnDefer* defer, hipStream_t s);
+// Per-sample affine of the A operand inside the transposed-read wgrad kernel (the project conv of a Conv1DBlock, c5:41-89): the operand the
+// forward pass multiplied was A'[m,k] = A[m,k] * P[b,k] + Q[b,k] (BatchNorm . ECA gate . drop-path, b = m / T), but only A is in memory.
+// The kernel accumulates A_b^T B_b per sample, folds it into the total with P[b,:] (and Q[b,:] x the sample's column sums of B) at every
+// sample boundary, and from the same per-sample accumulator emits what the BatchNorm / ECA backward needs from the gradient of A'
+// (dA' = rs[b] * B W^T, never read back): Rpart[b][p][k] = sum over the 64-column group p of W[k,n] * (A_b^T B_b)[k,n], i.e. partial
+// sums of sum_t dA'[b,t,k] * A[b,t,k] / rs[b], and G[b,n] = sum_t B[b,t,n].
+struct TnPsa { const float* P = nullptr; const float* Q = nullptr;     // [B, Ka]
+               const void* W = nullptr; int ldw = 0;                     // bf16 [Ka][ldw]: the dgrad's weight shadow
+               float* G = nullptr; float* Rpart = nullptr; int T = 0;     // [B, Nb], [B][Nb / 64][Ka]
+               int dbg = 0; };                                           // timing ablation (ISHARA_PSA_DBG; results are wrong): 1 no per-sample work, 2 no column sums, 4 no setup loads, 16 no write-out
+bool gemm_tn_psa_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, int T);
 int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, const void* B,
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
                    const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0, int nb_valid = 0,
-                   const float* bias_rowscale = nullptr, int bias_T = 0, TnDefer* defer = nullptr);   // bias_rowscale: dbias = sum_m bias_rowscale[m / bias_T] * B[m,:] (gemm_tn_bias_rowscale_ok shapes only); ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
+                   const float* bias_rowscale = nullptr, int bias_T = 0, TnDefer* defer = nullptr, const TnPsa* psa = nullptr);   // bias_rowscale: dbias = sum_m bias_rowscale[m / bias_T] * B[m,:] (gemm_tn_bias_rowscale_ok shapes only); ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
 // xb[M, Kp] (bf16) = x[M, F] (f32), zero padded to Kp columns (F % 4 == 0, Kp % 8 == 0)
 int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s);
 
@@ -143,9 +154,14 @@ int launch_map_rows(int dt, int op, const void* x, void* y, const float* rs, Dro
 int launch_sample_reduce(int dt, const void* dy, const void* other, const float* mean, const float* rstd,
                          float* S1, float* S2, int B, int T, int C, hipStream_t s);
 // Conv1DBlock BN+ECA backward finalize (one block; small)
-int launch_eca_bn_bwd_finalize(const float* S1, const float* S2, const float* gap, const float* gn, const float* sgate,
+// PsaStats: S1, S2 are not inputs but computed first, per sample, from what the per-sample-affine weight-gradient GEMM emitted (TnPsa):
+// S1[b,c] = rs[b] * sum_n Wt[n,c] G[b,n] (= sum_t dh4[b,t,c]), S2[b,c] = rstd[c] * (rs[b] * sum_p Rpart[b][p][c] - mean[c] * S1[b,c]); Wt = bf16 [N][ldt]
+struct PsaStats { const float* G = nullptr; const float* Rpart = nullptr; int nparts = 0; const void* Wt = nullptr; int ldt = 0, N = 0;
+                  const float* rs = nullptr; const float* mean = nullptr; const float* rstd = nullptr; };
+int launch_eca_bn_bwd_finalize(float* S1, float* S2, const float* gap, const float* gn, const float* sgate,
                                const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part /* B*8 floats */, int B, int T, int C, hipStream_t s);
+                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part /* B*8 floats */, int B, int T, int C, hipStream_t s,
+                               const PsaStats* ps = nullptr);
 // plain BN backward finalize from per-sample S1,S2: dgamma, dbeta, E[c] = -dbeta/Mtot, Fc = dgamma/Mtot
 int launch_bn_bwd_finalize(const float* S1, const float* S2, float* dgamma, float* dbeta, float* Ecol, float* Fc,
                            int B, int T, int C, hipStream_t s);

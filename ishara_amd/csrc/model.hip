@@ -278,6 +278,8 @@ static void plan_workspace(ishara_model* m) {
     m->S1 = m->f32((size_t)B * maxc); m->S2 = m->f32((size_t)B * maxc); m->E = m->f32((size_t)B * maxc);
     m->Fc = m->f32(maxc); m->Ecol = m->f32(maxc); m->ecap = m->f32((size_t)B * 8);
     m->dse = m->f32((size_t)B * d); m->dgapT = m->f32((size_t)B * d);
+    m->psa_on = m->dt == DT_BF16 && !m->convs.empty() && getenv("ISHARA_NO_PSA") == nullptr;
+    if (m->psa_on) { m->psaG = m->f32((size_t)B * d); m->psaR = m->f32((size_t)B * (size_t)((d + 63) / 64) * 2 * d); }
     size_t slabf = 0;
     for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > slabf) slabf = f; }
     if (m->stem_kp) { const size_t f = gemm_tn_slab_floats((int)Mx, m->stem_kp, d, m->dt); if (f > slabf) slabf = f; }
@@ -476,17 +478,17 @@ int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* 
     return 0;
 }
 int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid, int nb_valid,
-               const float* bias_rowscale, int bias_T) {
+               const float* bias_rowscale, int bias_T, const TnPsa* psa) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
     // the GEMM kernel and the sums of its split-M slabs are profiled under separate keys (the kernel's key is its rocprof name)
     if (m->tn_defer_on && !m->prof.on) {       // the sums of this GEMM's slabs ride with the next weight-gradient GEMM (gemm.hip, TnDefer)
         m->tn_defer.slab[0] = m->Wf(m->slab2[0]); m->tn_defer.slab[1] = m->Wf(m->slab2[1]);
-        return launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T, &m->tn_defer);
+        return launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T, &m->tn_defer, psa);
     }
     g_tn_phase = 1;
-    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T));
+    CKP(m, gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T, nullptr, psa));
     g_tn_phase = 2;
-    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T));
+    CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T, nullptr, psa));
     g_tn_phase = 0;
     return 0;
 }
@@ -528,7 +530,7 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     // the incoming gradient: dgrad scales its OUTPUT rows, wgrad multiplies h4^T by the plain gradient and weights the bias sum.
     const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
     EpiArgs e2; e2.resid = x;
-    cb.folded = false;
+    cb.folded = false; cb.psa = false;
     if (ds.thr) {                                        // rs[b] itself is drawn by eca_fwd below (one launch less per block)
         e2.rowscale = m->Wf(cb.rs); e2.T = T;
         EpiArgs probe = e2; probe.bias = m->P(cb.W2.b);
@@ -543,7 +545,10 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
         EpiArgs probe = e2; probe.pa_P = m->Wf(cb.P); probe.pa_Q = m->Wf(cb.Q); probe.T = T; probe.bias = m->P(cb.W2.b);
         probe.pro_out = r.training ? m->W(cb.h4) : nullptr;
         if (gemm_nt_as_prologue_ok(dt, dt, dt, r.M, cb.W2.N, cb.W2.K, cb.W2.ldt, probe)) {
-            e2.pa_P = m->Wf(cb.P); e2.pa_Q = m->Wf(cb.Q); e2.T = T; e2.pro_out = r.training ? m->W(cb.h4) : nullptr;
+            // training: h4 is written only when the backward pass needs it in memory — not when the project conv's weight-gradient GEMM applies
+            // P, Q itself (gemm.hip TnPsa: whole samples per M-split; the drop-path scale, if any, must be the folded one)
+            cb.psa = r.training && m->psa_on && (!ds.thr || cb.folded) && gemm_tn_psa_ok(dt, dt, dt, r.M, cb.W2.K, cb.W2.N, T);
+            e2.pa_P = m->Wf(cb.P); e2.pa_Q = m->Wf(cb.Q); e2.T = T; e2.pro_out = (r.training && !cb.psa) ? m->W(cb.h4) : nullptr;
             CK(gemm_fwd(m, cb.W2, m->W(cb.h2), dt, m->W(cb.out), dt, r.M, OP_NONE, no, e2));
             return 0;
         }
@@ -680,7 +685,14 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
     const DropSpec ds = dspec(r, cb.site, m->cfg.dropout_rate);
     const void* gs = g;                                  // gradient through the drop-path: dY * rs[b]
     EpiArgs e1;
-    if (ds.thr && cb.folded) {                           // h4 carries rs[b] (conv_fwd): dh4 = (g W2^T) * rs[b]; dW2 = h4^T g; db2 = sum_m rs[b(m)] g[m]
+    if (cb.psa) {                                        // h4 was never written: dW2 = sum_b diag(P_b) h2_b^T g_b + Q_b x colsum(g_b) inside the GEMM, which
+        const float* rs = ds.thr ? m->Wf(cb.rs) : nullptr;   // also emits the statistics of dh4 (S1, S2 below) — no pass over dh4 and h2
+        if (rs) { e1.rowscale = rs; e1.T = T; }
+        CK(gemm_dgrad(m, cb.W2, g, dt, m->W(m->t1), r.M, OP_NONE, no, e1));
+        TnPsa ps; ps.P = m->Wf(cb.P); ps.Q = m->Wf(cb.Q); ps.W = m->ws + cb.W2.wn; ps.ldw = cb.W2.ldn; ps.G = m->Wf(m->psaG); ps.Rpart = m->Wf(m->psaR); ps.T = T;
+        { static const int psa_dbg = getenv("ISHARA_PSA_DBG") ? atoi(getenv("ISHARA_PSA_DBG")) : 0; ps.dbg = psa_dbg; }
+        CK(gemm_wgrad(m, cb.W2, m->W(cb.h2), dt, OP_NONE, no, g, dt, OP_NONE, no, r.M, 0, 0, rs, rs ? T : 0, &ps));
+    } else if (ds.thr && cb.folded) {                    // h4 carries rs[b] (conv_fwd): dh4 = (g W2^T) * rs[b]; dW2 = h4^T g; db2 = sum_m rs[b(m)] g[m]
         e1.rowscale = m->Wf(cb.rs); e1.T = T;
         CK(gemm_dgrad(m, cb.W2, g, dt, m->W(m->t1), r.M, OP_NONE, no, e1));
         CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, g, dt, OP_NONE, no, r.M, 0, 0, m->Wf(cb.rs), T));
@@ -692,9 +704,12 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
         CK(gemm_dgrad(m, cb.W2, gs, dt, m->W(m->t1), r.M, OP_NONE, no, e1));                       // dh4
         CK(gemm_wgrad(m, cb.W2, m->W(cb.h4), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
     }
-    CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
+    if (!cb.psa) CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, c, m->s));
+    PsaStats pst;                                        // cb.psa: S1, S2 come out of the finalize kernel itself (from G and Rpart)
+    if (cb.psa) { pst.G = m->Wf(m->psaG); pst.Rpart = m->Wf(m->psaR); pst.nparts = cb.W2.N / 64; pst.Wt = m->ws + cb.W2.wt; pst.ldt = cb.W2.ldt; pst.N = cb.W2.N;
+                  pst.rs = ds.thr ? m->Wf(cb.rs) : nullptr; pst.mean = m->Wf(cb.mean); pst.rstd = m->Wf(cb.rstd); }
     CKP(m, "eca_bn_bwd_finalize", 0, 0, launch_eca_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->Wf(cb.ssum), m->Wf(cb.gn), m->Wf(cb.sg), m->P(cb.eca), m->P(cb.bn.gamma), m->P(cb.bn.beta),
-                                  m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), m->Wf(m->ecap), B, T, c, m->s));
+                                  m->Wf(cb.mean), m->Wf(cb.rstd), m->G(cb.bn.gamma), m->G(cb.bn.beta), m->G(cb.eca), m->Wf(m->E), m->Wf(m->Fc), m->Wf(m->ecap), B, T, c, m->s, cb.psa ? &pst : nullptr));
     // BatchNorm backward applied inside the depthwise-conv backward (one pass over dh4, h2 and z1); shapes without the fused kernel
     // take the two-kernel path
     DwBnArgs bn; bn.h = m->W(cb.h2); bn.mean = m->Wf(cb.mean); bn.rstd = m->Wf(cb.rstd); bn.a = m->Wf(cb.a); bn.sg = m->Wf(cb.sg); bn.E = m->Wf(m->E); bn.Fc = m->Wf(m->Fc); bn.e_per_sample = 1;

@@ -46,6 +46,8 @@ struct ConvBlock {
     DenseW W1, W2; int dw = -1, eca = -1; BNp bn; int k = 0; uint32_t site = 0;
     Buf z1, h2, h4, out, ssum, ssq, mean, rstd, a, bsh, gn, sg, P, Q, rs;
     bool folded = false;      // last training forward folded the drop-path scale into h4 (= rs[b] * (h2 P + Q)): see conv_fwd
+    bool psa = false;         // last training forward did not write h4: the project conv's weight gradient applies the per-sample affine itself
+                              // and emits the BatchNorm / ECA backward statistics (gemm.hip, TnPsa)
 };
 struct FFN {
     Norm ln; float eps; DenseW Wa, Wb; uint32_t site_in = 0, site_out = 0; bool has_out_drop = false;
@@ -122,6 +124,7 @@ struct ishara_model {
     // temps
     TnDefer tn_defer; Buf slab2[2]; bool tn_defer_on = false;      // deferred wgrad slab sums (gemm.hip): two alternating slab buffers
     Buf gA, gB, t1, t2, t3, S1, S2, E, Fc, Ecol, ecap, dse, dgapT, slab, ctcws, dlogits, nllb, delta;
+    Buf psaG, psaR; bool psa_on = false;   // TnPsa outputs: G [B, d], Rpart [B][d / 64][2d]
     size_t shadow_begin = 0, shadow_end = 0;
     size_t shadow_tab_off = 0;             // device descriptor table of the batched shadow build, inside the workspace (no
                                            // hipMalloc/hipFree of our own: a hipFree from a garbage-collected model would break a
@@ -185,7 +188,7 @@ void plan_shadow(ishara_model* m, DenseW& w, int min_ldt = 0, int min_ldn = 0);
 int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea);
 int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* dX, int M, int aop, const OpArgs& oa, const EpiArgs& ea);
 int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid = 0, int nb_valid = 0,
-               const float* bias_rowscale = nullptr, int bias_T = 0);
+               const float* bias_rowscale = nullptr, int bias_T = 0, const TnPsa* psa = nullptr);
 int wgrad_flush(ishara_model* m);
 int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x);
 int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn);

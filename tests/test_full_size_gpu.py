@@ -86,3 +86,38 @@ def test_ctc_loss_is_permutation_equivariant(models):
     nll_p = mb.ctc_loss(y[perm], logits[perm])
     assert torch.allclose(nll_p, nll[perm], rtol=1e-6, atol=1e-4)
     assert (nll > 0).all() and torch.isfinite(nll).all()
+
+
+def test_project_conv_wgrad_per_sample_affine_matches_materialised_operand(models):
+    """Conv1DBlock backward, two routes: (a) the project conv's weight-gradient GEMM reads h2 and applies the per-sample affine
+    (BatchNorm . ECA gate . drop-path) to its per-sample accumulators, emitting the BatchNorm / ECA statistics of dh4 on the way
+    (gemm.hip TnPsa: 32 M-splits of 2 samples at B = 64); (b) ISHARA_NO_PSA: h4 is written by the forward pass, the GEMM reads it,
+    and a separate pass over dh4 and h2 produces the statistics.  Same weights, batch and dropout seed: the logits are bit-identical
+    (the forward pass differs only in what it stores) and the gradients agree to bf16 rounding of dh4 / h4."""
+    import os
+    mb, _ = models
+    x, y = _data(9)
+    os.environ["ISHARA_NO_PSA"] = "1"
+    try:
+        ma = get_model(**KW, dropout_rate=0.2, dtype="bf16", max_batch=B, seed=0)
+    finally:
+        del os.environ["ISHARA_NO_PSA"]
+    ma.set_weights(mb.get_weights())
+    lb, lgb = mb.loss_and_gradients(x, y, seed=13); gb = mb.grads.clone(); lgb = lgb.clone()
+    la, lga = ma.loss_and_gradients(x, y, seed=13); ga = ma.grads.clone()
+    assert torch.equal(lga, lgb) and float(la.item()) == float(lb.item())
+    rel = ((ga - gb).norm() / ga.norm()).item()
+    assert rel <= 2e-2, f"flat gradient rel-L2 between the two routes {rel}"
+    worst = 0.0
+    worst_name = ""
+    for name, shape, off, trainable in mb.entries:
+        if not trainable:
+            continue
+        n = int(np.prod(shape))
+        a, b_ = ga[off:off + n], gb[off:off + n]
+        den = a.norm().item()
+        if den > 0:
+            e = (a - b_).norm().item() / den
+            if e > worst:
+                worst, worst_name = e, name
+    assert worst <= 6e-2, f"worst per-parameter rel-L2 {worst} ({worst_name})"
