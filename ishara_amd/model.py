@@ -205,10 +205,20 @@ class Model:
         _lib.check(self._lib.ishara_sync_weights(self._h, _stream()), "ishara_sync_weights")
 
     def save_weights(self, path: str):
-        """model.save_weights (c9:10).  Interchange format: .npz keyed by Keras-style names."""
+        """model.save_weights (c9:10).  `*.h5` / `*.hdf5`: the Keras-2 save_weights HDF5 layout, written through the image's HDF5
+        library (keras_h5.py); anything else: .npz keyed by the library's Keras-style names."""
+        if path.endswith((".h5", ".hdf5")):
+            from . import keras_h5
+            keras_h5.save_weights_h5(path, self.get_weights(), [(n, tuple(s)) for n, s, _, _ in self.entries])
+            return
         np.savez(path if path.endswith(".npz") else path + ".npz", **self.get_weights())
 
     def load_weights(self, path: str):
+        """model.load_weights: a Keras-2 `.h5` weights file (matched by layer / weight order and shape, like by_name=False) or the .npz."""
+        if path.endswith((".h5", ".hdf5")):
+            from . import keras_h5
+            self.set_weights(keras_h5.load_weights_h5(path, [(n, tuple(s)) for n, s, _, _ in self.entries]))
+            return
         with np.load(path if path.endswith(".npz") else path + ".npz") as z:
             self.set_weights({k: z[k] for k in z.files})
 
