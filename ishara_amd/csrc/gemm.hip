@@ -1803,6 +1803,13 @@ static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, flo
         if (splits <= 0 || g_dbg_tn) { ishara_set_error("gemm_tn: no per-sample-affine plan for M=%d T=%d (gemm_tn_psa_ok)", M, psa->T); return -1; }
         rps = M / splits;
     }
+    if (defer && g_tn_phase == 0 && !g_dbg_tn && tiles * splits > 256 && !psa) {
+        // a launch that fills the chip twice over (12+ tiles at two workgroups per CU) neither carries riders nor defers its own sums: the riders
+        // would queue behind 512 workgroups and its slabs (2 MB x 16 splits for a 1024 x 512 weight) make the next launch's riders the tail
+        // (configs[3]: 47.9 -> 51.5 ms/step with the deferral on everywhere)
+        launch_gemm_tn_flush(defer, s);
+        defer = nullptr;
+    }
     if (defer && g_tn_phase == 0 && !g_dbg_tn) {
         // deferred sums: this launch writes the slab buffer whose turn it is, and carries the sums of the previous launch's slabs
         slab = defer->slab[defer->turn];
