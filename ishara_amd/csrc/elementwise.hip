@@ -1243,100 +1243,115 @@ int launch_col_affine(int dt, const void* x, const float* a, const float* b, voi
 // BatchNorm backward pieces
 // =====================================================================================
 // Conv1DBlock (BN -> ECA): step 1, per sample.  E <- dgn[b,c]; dw5 += sum dz*gn(shifted)
-// ps.G != nullptr (PsaStats, kernels.h): S1, S2 of this sample are first computed from what the per-sample-affine weight-gradient GEMM
-// emitted — S1[c] = rs * sum_n Wt[n,c] G[n], S2[c] = rstd[c] * (rs * sum_p Rpart[p][c] - mean[c] * S1[c]) — by the same workgroup: thread
-// (cg, w) takes 8 channels (16-byte weight loads, channel = fast index) and a quarter of the N weight rows, 32 loads in flight (one thread
-// per channel over all N sat on load latency: 37 us as a kernel of its own)
+// grid = (B, channel chunks of CC): a workgroup owns CC channels of one sample (the 5-tap channel convolution reaches 2 channels into the
+// neighbouring chunks).  ps.G != nullptr (PsaStats, kernels.h): S1, S2 are first computed from what the per-sample-affine weight-gradient
+// GEMM emitted — S1[c] = rs * sum_n Wt[n,c] G[n], S2[c] = rstd[c] * (rs * sum_p Rpart[p][c] - mean[c] * S1[c]) — for the chunk and one
+// 8-channel group of halo on each side (kept in LDS; only the chunk's own values are written out): thread (cg, w) takes 8 channels (16-byte
+// weight loads, channel = fast index) and a quarter of the N weight rows, 32 loads in flight (one thread per channel over all N sat on load
+// latency: 37 us as a kernel of its own; one workgroup per sample over all channels: 32 us at C = 1024, B = 64)
 __global__ __launch_bounds__(256) void eca_bwd_sample_kernel(float* __restrict__ S1, float* __restrict__ S2,
                                                              const float* __restrict__ gn, const float* __restrict__ sg,
                                                              const float* __restrict__ w5, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ E,
-                                                             float* __restrict__ dw5part, int C, PsaStats ps) {
-    extern __shared__ float sh[];   // dz[C+4], g[C+4]  (PsaStats: first G[N] | partial sums [4][C])
-    float* dz = sh;
-    float* g = sh + C + 4;
+                                                             float* __restrict__ dw5part, int C, int CC, PsaStats ps) {
+    extern __shared__ float sh[];
+    const int CH = CC + 16;
+    float* dz = sh;                 // [CC + 4]: channel c_lo - 2 + i
+    float* g = dz + CC + 4;         // [CC + 4]
+    float* s1l = g + CC + 4;        // [CH]: channel c_lo - 8 + i
+    float* s2l = s1l + CH;
+    float* gl = s2l + CH;           // [N]
     __shared__ float wred[5][4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, c_lo = (int)blockIdx.y * CC, c_hi = min(C, c_lo + CC);
     if (ps.G) {
         const int N = ps.N, cg = threadIdx.x & 63, w = threadIdx.x >> 6;
-        float* gl = sh;                 // [N]
-        float* part = sh + N;           // [4][C]
+        float* part = gl + N;       // [4][CH]
         for (int n = threadIdx.x; n < N; n += 256) gl[n] = ps.G[(size_t)b * N + n];
         const bf16* Wt = reinterpret_cast<const bf16*>(ps.Wt);
         const int nq = (N + 3) / 4, nbeg = w * nq, nend = min(N, nbeg + nq);
         __syncthreads();
-        for (int c0 = cg * 8; c0 < C; c0 += 512) {
+        for (int i0 = cg * 8; i0 < CH; i0 += 512) {
+            const int c0 = c_lo - 8 + i0;
             float a[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = 0.f;
-            for (int n = nbeg; n < nend; n += 32) {
-                bf16x8 wv[32];
+            if (c0 >= 0 && c0 < C) {
+                for (int n = nbeg; n < nend; n += 32) {
+                    bf16x8 wv[32];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) wv[u] = *reinterpret_cast<const bf16x8*>(Wt + (size_t)min(n + u, nend - 1) * ps.ldt + c0);
+                    for (int u = 0; u < 32; ++u) wv[u] = *reinterpret_cast<const bf16x8*>(Wt + (size_t)min(n + u, nend - 1) * ps.ldt + c0);
 #pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const float gv = n + u < nend ? gl[n + u] : 0.f;
+                    for (int u = 0; u < 32; ++u) {
+                        const float gv = n + u < nend ? gl[n + u] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] += (float)wv[u][e] * gv;
+                        for (int e = 0; e < 8; ++e) a[e] += (float)wv[u][e] * gv;
+                    }
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part[w * C + c0 + e] = a[e];
+            for (int e = 0; e < 8; ++e) part[w * CH + i0 + e] = a[e];
         }
         __syncthreads();
         const float r = ps.rs ? ps.rs[b] : 1.f;
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float R = 0.f;
-            for (int p = 0; p < ps.nparts; ++p) R += ps.Rpart[((size_t)b * ps.nparts + p) * C + c];
-            const float s1 = r * (part[c] + part[C + c] + part[2 * C + c] + part[3 * C + c]);
-            S1[(size_t)b * C + c] = s1;
-            S2[(size_t)b * C + c] = ps.rstd[c] * (r * R - ps.mean[c] * s1);
+        for (int i = threadIdx.x; i < CH; i += 256) {
+            const int c = c_lo - 8 + i;
+            float s1 = 0.f, s2 = 0.f;
+            if (c >= 0 && c < C) {
+                float R = 0.f;
+                for (int p = 0; p < ps.nparts; ++p) R += ps.Rpart[((size_t)b * ps.nparts + p) * C + c];
+                s1 = r * (part[i] + part[CH + i] + part[2 * CH + i] + part[3 * CH + i]);
+                s2 = ps.rstd[c] * (r * R - ps.mean[c] * s1);
+                if (c >= c_lo && c < c_hi) { S1[(size_t)b * C + c] = s1; S2[(size_t)b * C + c] = s2; }
+            }
+            s1l[i] = s1; s2l[i] = s2;
         }
-        __syncthreads();                // S1, S2 of this sample are visible to the workgroup; sh is free again
+        __syncthreads();
     }
-    for (int c = threadIdx.x; c < C + 4; c += blockDim.x) {
-        const int cc = c - 2;
+    for (int i = threadIdx.x; i < CC + 4; i += blockDim.x) {
+        const int cc = c_lo - 2 + i;
         float z = 0.f, gg = 0.f;
         if (cc >= 0 && cc < C) {
-            const size_t i = (size_t)b * C + cc;
-            const float ds = gamma[cc] * S2[i] + beta[cc] * S1[i];
-            const float sv = sg[i];
+            const size_t idx = (size_t)b * C + cc;
+            const float s1 = ps.G ? s1l[i + 6] : S1[idx], s2 = ps.G ? s2l[i + 6] : S2[idx];
+            const float ds = gamma[cc] * s2 + beta[cc] * s1;
+            const float sv = sg[idx];
             z = ds * sv * (1.f - sv);
-            gg = gn[i];
+            gg = gn[idx];
         }
-        dz[c] = z; g[c] = gg;
+        dz[i] = z; g[i] = gg;
     }
     __syncthreads();
     float wp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        // dgn[c] = sum_j w5[j] * dz[c - j + 2]  -> padded index (c - j + 2) + 2
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
+        const int li = c - c_lo;
+        // dgn[c] = sum_j w5[j] * dz(channel c - j + 2)  -> local index li - j + 4
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) acc += w5[j] * dz[c - j + 4];
+        for (int j = 0; j < 5; ++j) acc += w5[j] * dz[li - j + 4];
         E[(size_t)b * C + c] = acc;
-        // dw5[j] += dz[c] * gn[c + j - 2] -> padded g index c + j
-        const float z = dz[c + 2];
+        // dw5[j] += dz(c) * gn(c + j - 2) -> local index li + j
+        const float z = dz[li + 2];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) wp[j] += z * g[c + j];
+        for (int j = 0; j < 5; ++j) wp[j] += z * g[li + j];
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 5; ++j) { const float v = wave_sum(wp[j]); if (lane == 0) wred[j][wid] = v; }
     __syncthreads();
-    if (threadIdx.x < 5) dw5part[(size_t)b * 8 + threadIdx.x] = wred[threadIdx.x][0] + wred[threadIdx.x][1] + wred[threadIdx.x][2] + wred[threadIdx.x][3];   // summed over samples, in order, by the channel kernel
+    if (threadIdx.x < 5) dw5part[((size_t)b * gridDim.y + blockIdx.y) * 8 + threadIdx.x] = wred[threadIdx.x][0] + wred[threadIdx.x][1] + wred[threadIdx.x][2] + wred[threadIdx.x][3];   // summed in order by the channel kernel
 }
 
 // step 2, per channel (FIN_CL channels x FIN_BL sample lanes per block): dgamma, dbeta, Fc; E[b,c] <- dgn/T - dbeta/Mtot
 __global__ __launch_bounds__(1024) void eca_bn_bwd_channel_kernel(const float* __restrict__ S1, const float* __restrict__ S2, const float* __restrict__ gap,
                                           const float* __restrict__ sg, const float* __restrict__ mean, const float* __restrict__ rstd,
                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ E, float* __restrict__ Fc,
-                                          const float* __restrict__ dw5part, float* __restrict__ dw5, int B, int Tn, int C) {
+                                          const float* __restrict__ dw5part, int nparts5, float* __restrict__ dw5, int B, int Tn, int C) {
     __shared__ double rg_[FIN_NW][FIN_CL], rb_[FIN_NW][FIN_CL];
     __shared__ float eb_[FIN_CL];
-    if (blockIdx.x == 0 && threadIdx.x < 5 * 64) {      // ECA tap gradient: per-sample partials of step 1, summed in a fixed order (wave j = tap j)
+    if (blockIdx.x == 0 && threadIdx.x < 5 * 64) {      // ECA tap gradient: per-(sample, chunk) partials of step 1, summed in a fixed order (wave j = tap j)
         const int j = threadIdx.x >> 6, l = threadIdx.x & 63;
         float a = 0.f;
-        for (int b = l; b < B; b += 64) a += dw5part[(size_t)b * 8 + j];
+        for (int b = l; b < nparts5; b += 64) a += dw5part[(size_t)b * 8 + j];
         a = wave_sum(a);
         if (l == 0) dw5[j] += a;
     }
@@ -1375,10 +1390,10 @@ int launch_eca_bn_bwd_finalize(float* S1, float* S2, const float* gap, const flo
                                float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part, int B, int T, int C, hipStream_t s, const PsaStats* ps) {
     PsaStats p = ps ? *ps : PsaStats{};
     if (p.G && (C % 8 != 0 || p.ldt % 8 != 0 || ((uintptr_t)p.Wt) % 16 != 0)) { ishara_set_error("eca_bn_bwd_finalize: PsaStats needs C %% 8 == 0 and 16-byte aligned weight rows"); return -1; }
-    size_t shm = 2 * (C + 4) * sizeof(float);
-    if (p.G && (size_t)(p.N + 4 * C) * sizeof(float) > shm) shm = (size_t)(p.N + 4 * C) * sizeof(float);
-    hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B), dim3(256), shm, s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5part, C, p);
-    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, dw5part, dw5, B, T, C);
+    const int CC = (C > 256 && C % 256 == 0 && C / 256 <= ECA_MAX_CHUNKS) ? 256 : C, nchunk = C / CC;      // dw5part: B * nchunk * 8 floats
+    const size_t shm = (size_t)(2 * (CC + 4) + 2 * (CC + 16) + (p.G ? p.N + 4 * (CC + 16) : 0)) * sizeof(float);
+    hipLaunchKernelGGL(eca_bwd_sample_kernel, dim3(B, nchunk), dim3(256), shm, s, S1, S2, gn, sgate, w5, gamma, beta, E, dw5part, C, CC, p);
+    hipLaunchKernelGGL(eca_bn_bwd_channel_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, S1, S2, gap, sgate, mean, rstd, dgamma, dbeta, E, Fc, dw5part, B * nchunk, dw5, B, T, C);
     return LAUNCH_OK();
 }
 

@@ -156,11 +156,12 @@ int launch_sample_reduce(int dt, const void* dy, const void* other, const float*
 // Conv1DBlock BN+ECA backward finalize (one block; small)
 // PsaStats: S1, S2 are not inputs but computed first, per sample, from what the per-sample-affine weight-gradient GEMM emitted (TnPsa):
 // S1[b,c] = rs[b] * sum_n Wt[n,c] G[b,n] (= sum_t dh4[b,t,c]), S2[b,c] = rstd[c] * (rs[b] * sum_p Rpart[b][p][c] - mean[c] * S1[b,c]); Wt = bf16 [N][ldt]
+#define ECA_MAX_CHUNKS 4          // eca_bwd_sample_kernel splits the channels of a sample over up to 4 workgroups: dw5part holds B * 4 * 8 floats
 struct PsaStats { const float* G = nullptr; const float* Rpart = nullptr; int nparts = 0; const void* Wt = nullptr; int ldt = 0, N = 0;
                   const float* rs = nullptr; const float* mean = nullptr; const float* rstd = nullptr; };
 int launch_eca_bn_bwd_finalize(float* S1, float* S2, const float* gap, const float* gn, const float* sgate,
                                const float* w5, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part /* B*8 floats */, int B, int T, int C, hipStream_t s,
+                               float* dgamma, float* dbeta, float* dw5, float* E, float* Fc, float* dw5part /* B * ECA_MAX_CHUNKS * 8 floats */, int B, int T, int C, hipStream_t s,
                                const PsaStats* ps = nullptr);
 // plain BN backward finalize from per-sample S1,S2: dgamma, dbeta, E[c] = -dbeta/Mtot, Fc = dgamma/Mtot
 int launch_bn_bwd_finalize(const float* S1, const float* S2, float* dgamma, float* dbeta, float* Ecol, float* Fc,

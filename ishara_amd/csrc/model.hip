@@ -276,7 +276,7 @@ static void plan_workspace(ishara_model* m) {
     m->t1 = m->act(maxw); m->t2 = m->act(maxw); m->t3 = m->act(maxw);
     const int maxc = 2 * d > maxw ? 2 * d : maxw;
     m->S1 = m->f32((size_t)B * maxc); m->S2 = m->f32((size_t)B * maxc); m->E = m->f32((size_t)B * maxc);
-    m->Fc = m->f32(maxc); m->Ecol = m->f32(maxc); m->ecap = m->f32((size_t)B * 8);
+    m->Fc = m->f32(maxc); m->Ecol = m->f32(maxc); m->ecap = m->f32((size_t)B * 8 * ECA_MAX_CHUNKS);
     m->dse = m->f32((size_t)B * d); m->dgapT = m->f32((size_t)B * d);
     m->psa_on = m->dt == DT_BF16 && !m->convs.empty() && getenv("ISHARA_NO_PSA") == nullptr;
     if (m->psa_on) { m->psaG = m->f32((size_t)B * d); m->psaR = m->f32((size_t)B * (size_t)((d + 63) / 64) * 2 * d); }
