@@ -21,12 +21,18 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #define AF_VLD 72    // V^T tile row stride (64 keys + 8 pad): 144-B rows make the 8-byte fragment reads conflict-free
 #define AF_PAD 8     // row-major [64][DH] tiles get DH+8 columns (80-B / 144-B rows): conflict-free 16-byte fragment reads
 
-DEVI uint32_t pk2(float lo, float hi) {
+DEVI uint32_t pk2(float lo, float hi) {      // ONE v_cvt_pk_bf16_f32 (element-wise casts compile to two of them and a v_perm_b32)
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 t; t[0] = (bf16)lo; t[1] = (bf16)hi;
-    return __builtin_bit_cast(uint32_t, t);
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
+
+// keepbits |= the four keep flags at bit positions sh .. sh+3 (sh is a compile-time constant after unrolling)
+DEVI void constexpr_shift_or(uint32_t& bits, bool k0, bool k1, bool k2, bool k3, int sh) {
+    bits |= (k0 ? (1u << sh) : 0u) | (k1 ? (2u << sh) : 0u) | (k2 ? (4u << sh) : 0u) | (k3 ? (8u << sh) : 0u);
+}
 
 // XCD-aware workgroup -> (head bh, block xb) mapping.  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with
 // its own L2; the nxb query (key) blocks of one (batch, head) all stream the SAME K/V (Q/dO) rows, so they are given ids
@@ -143,16 +149,23 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
         // ---- online softmax per query tile; lane = (query c, keys 16kt + 4g + r)
         typename af_vec<E>::v8 pb[2][2];
         uint32_t keepbits = 0u;          // bit 16t + 4kt + r: dropout keep flag of (query tile t, key 16kt + 4g + r)
+        if (partial) {                   // a real (uniform) branch: as a per-score select this cost 32 v_cndmask + 15 v_cmp in EVERY chunk
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + 16 * kt + 4 * g + r >= Tn) sacc[kt][t][r] = -1e30f;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float mx = -1e30f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (partial && key0 + 16 * kt + 4 * g + r >= Tn) sacc[kt][t][r] = -1e30f;
-                    mx = fmaxf(mx, sacc[kt][t][r]);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][t][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m_run[t], mx);
@@ -173,10 +186,14 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
                     p[kt][r] = pv;
                 }
                 if constexpr (DM != 0) {      // 4 consecutive keys: 2 hashes; the keep bits are remembered for the backward kernels
-                    const uint32_t kb4 = rng_bits4(rkey, (uint32_t)(key0 + 16 * kt + 4 * g), drop.thr);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p[kt][r] = ((kb4 >> r) & 1u) ? p[kt][r] : 0.f;      // the 1/(1-rate) factor is applied once per output below
-                    keepbits |= kb4 << (16 * t + 4 * kt);
+                    // one compare per score serves both the select and the bit (the 1/(1-rate) factor is applied once per output below)
+                    const uint32_t col4 = (uint32_t)(key0 + 16 * kt + 4 * g);
+                    const uint32_t h0 = rng_pair(rkey, col4), h1 = rng_pair(rkey, col4 + 2);
+                    const bool k0 = (h0 & 0xffffu) >= drop.thr, k1 = (h0 >> 16) >= drop.thr, k2 = (h1 & 0xffffu) >= drop.thr, k3 = (h1 >> 16) >= drop.thr;
+                    p[kt][0] = k0 ? p[kt][0] : 0.f; p[kt][1] = k1 ? p[kt][1] : 0.f; p[kt][2] = k2 ? p[kt][2] : 0.f; p[kt][3] = k3 ? p[kt][3] : 0.f;
+                    if constexpr (DM == 2) {
+                        constexpr_shift_or(keepbits, k0, k1, k2, k3, 16 * t + 4 * kt);
+                    }
                 }
             }
 #pragma unroll
@@ -790,16 +807,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_fused_kernel(const b
                     const uint32_t key = (uint32_t)(keyt + c);
                     // element (hq, r): query q0 + 32ks + 16hq + 4g + r, key keyt + c
                     float pd[2][4], ds[2][4];
+                    // DM == 2: the keep flag of element (hq, r) is bit 16hq + sh of mw[r]: one variable shift per r, then a sign-extending
+                    // bit-field extract gives the 0 / ~0 mask that is ANDed onto the two float values (and / compare / two selects before)
+                    uint32_t mws[4] = {0u, 0u, 0u, 0u};
+                    if constexpr (DM == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mws[r] = mw[r] >> sh;
+                    }
 #pragma unroll
                     for (int hq = 0; hq < 2; ++hq)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[hq][r], cs, nlv[hq][r]));
                             float dp = dpa[hq][r], pdv = pv;
-                            if constexpr (DM != 0) {
-                                const bool keep = DM == 2 ? ((mw[r] >> (16 * hq + sh)) & 1u) != 0u : rng_keep(rkv[hq][r], key, drop.thr);
+                            if constexpr (DM == 2) {
+                                const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)mws[r], 16 * hq, 1);
+                                dp = __uint_as_float(__float_as_uint(dp * drop.scale) & km);
+                                pdv = __uint_as_float(__float_as_uint(pv) & km);      // * drop.scale once per dV output
+                            } else if constexpr (DM != 0) {
+                                const bool keep = rng_keep(rkv[hq][r], key, drop.thr);
                                 dp = keep ? dp * drop.scale : 0.f;
-                                pdv = keep ? pv : 0.f;                       // * drop.scale once per dV output
+                                pdv = keep ? pv : 0.f;
                             }
                             pd[hq][r] = pdv;
                             ds[hq][r] = pv * (dp - dlv[hq][r]);              // * scale once per dK / dQ output
