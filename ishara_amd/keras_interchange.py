@@ -1,8 +1,8 @@
 """Weight interchange with the reference's Keras model.
 
-`model.save_weights("model.h5")` (conv-hybrid-model.ipynb c9:10) needs h5py / TensorFlow, neither of which exists in
-this image, so the interchange is the ORDERED LIST that Keras itself defines: `model.get_weights()` /
-`model.set_weights(list)`.  On the reference side (a maintainer with TensorFlow):
+`model.save_weights("model.h5")` (conv-hybrid-model.ipynb c9:10): the HDF5 file itself is handled by `keras_h5.py` (through the image's
+HDF5 C library); what goes INTO it — and what moves without HDF5 — is the ORDERED LIST that Keras itself defines:
+`model.get_weights()` / `model.set_weights(list)`.  On the reference side (a maintainer with TensorFlow):
 
     np.savez("ishara_keras_weights.npz", *model.get_weights())          # export -> arr_0, arr_1, ...
     model.set_weights([z[f"arr_{i}"] for i in range(len(z.files))])     # import

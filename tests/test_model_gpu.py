@@ -310,3 +310,23 @@ def test_keras_interchange_matches_model(tmp_path):
     assert np.abs(other(x, training=False).cpu().numpy() - a).max() > 1e-3
     other.load_keras_weights(p)
     assert np.array_equal(other(x, training=False).cpu().numpy(), a)
+
+
+def test_h5_weights_round_trip_through_the_model(tmp_path):
+    """model.save_weights("model.h5") / load_weights (c9:10): a second model with other weights gives the first one's logits bit for
+    bit after loading the Keras-layout HDF5 file (ishara_amd/keras_h5.py; skipped where the image has no libhdf5)."""
+    from ishara_amd import keras_h5
+    if not keras_h5.available():
+        pytest.skip("libhdf5 is not loadable in this environment")
+    from oracle import ishara_oracle as O
+    kw = CFGS["tiny"]
+    ocfg = _oracle_cfg(kw, 0.0)
+    model = _build(kw, "f32", 0.0)
+    p = str(tmp_path / "model.h5")
+    model.save_weights(p)
+    other = _build(kw, "f32", 0.0, seed=99)
+    x, _ = O.synthetic_batch(ocfg, kw["B"], seed=1)
+    a = model(x, training=False).cpu().numpy()
+    assert np.abs(other(x, training=False).cpu().numpy() - a).max() > 1e-3
+    other.load_weights(p)
+    assert np.array_equal(other(x, training=False).cpu().numpy(), a)
