@@ -1478,32 +1478,55 @@ int launch_bn_bwd_apply(int dt, const void* dy, const void* x, const float* mean
 // =====================================================================================
 // Squeeze-Excite MLP (one workgroup per sample; C <= 1024, R <= 128)
 // =====================================================================================
+// sum_i v[i0 + i * vstep] * w[i * wstride] over n terms, 16 weight loads in flight (these matvecs are chains of L2 latencies, not of bytes)
+DEVI float se_dot(const float* __restrict__ w, size_t wstride, const float* v, int vstep, int n) {
+    float acc = 0.f;
+    int i = 0;
+    for (; i + 16 <= n; i += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = w[(size_t)(i + u) * wstride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += t[u] * v[(i + u) * vstep];
+    }
+    for (; i < n; ++i) acc += w[(size_t)i * wstride] * v[i * vstep];
+    return acc;
+}
 __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ gap, float invT, const float* __restrict__ W1, const float* __restrict__ b1,
                                                      const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ hid_pre,
                                                      float* __restrict__ se, int C, int R) {
-    extern __shared__ float sh[];   // z[C], h[R]
+    extern __shared__ float sh[];   // z[C], h[R], part[256]
     float* z = sh;
     float* h = sh + C;
+    float* part = h + R;
     const int b = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += blockDim.x) z[c] = gap[(size_t)b * C + c] * invT;
     __syncthreads();
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
-        float acc = b1[r];
-        for (int c = 0; c < C; ++c) acc += z[c] * W1[(size_t)c * R + r];
-        hid_pre[(size_t)b * R + r] = acc;
-        h[r] = swishf_(acc);
+    if (R <= 256 && 256 % R == 0 && blockDim.x == 256) {      // the squeeze matvec over all 256 threads: thread (r, p) sums every (256 / R)-th channel
+        const int np = 256 / R, r = threadIdx.x % R, p = threadIdx.x / R;      // (R threads over all C channels: a 65 us chain of loads at C = 512)
+        part[p * R + r] = se_dot(W1 + (size_t)p * R + r, (size_t)np * R, z + p, np, (C - p + np - 1) / np);
+        __syncthreads();
+        if (threadIdx.x < R) {
+            float t = b1[r];
+            for (int q = 0; q < np; ++q) t += part[q * R + r];
+            hid_pre[(size_t)b * R + r] = t;
+            h[r] = swishf_(t);
+        }
+    } else {
+        for (int r = threadIdx.x; r < R; r += blockDim.x) {
+            float acc = b1[r];
+            for (int c = 0; c < C; ++c) acc += z[c] * W1[(size_t)c * R + r];
+            hid_pre[(size_t)b * R + r] = acc;
+            h[r] = swishf_(acc);
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc = b2[c];
-        for (int r = 0; r < R; ++r) acc += h[r] * W2[(size_t)r * C + c];
-        se[(size_t)b * C + c] = sigmoidf_(acc);
-    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) se[(size_t)b * C + c] = sigmoidf_(b2[c] + se_dot(W2 + c, (size_t)C, h, 1, R));
 }
 
 int launch_se_fwd(const float* gap, float invT, const float* W1, const float* b1, const float* W2, const float* b2,
                   float* hid_pre, float* se, int B, int C, int R, hipStream_t s) {
-    hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, gap, invT, W1, b1, W2, b2, hid_pre, se, C, R);
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(256), (C + R + 256) * sizeof(float), s, gap, invT, W1, b1, W2, b2, hid_pre, se, C, R);
     return LAUNCH_OK();
 }
 
@@ -1513,9 +1536,10 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ W1, const float* __restrict__ W2,
                                                      const float* __restrict__ hid_pre, const float* __restrict__ se,
                                                      float* __restrict__ scr, float* __restrict__ dgapT, int C, int R) {
-    extern __shared__ float sh[];   // dp2[C], dhp[R]
+    extern __shared__ float sh[];   // dp2[C], dhp[R], part[256]
     float* dp2 = sh;
     float* dhp = sh + C;
+    float* part = dhp + R;
     const int b = blockIdx.x;
     float* sb = scr + (size_t)b * (C + 2 * R);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -1526,21 +1550,33 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ d
         sb[c] = d;
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += W2[(size_t)r * C + c] * dp2[c];
-        const float hp = hid_pre[(size_t)b * R + r];
-        const float d = acc * dswishf_(hp);
-        dhp[r] = d;
-        sb[C + r] = d;
-        sb[C + R + r] = swishf_(hp);
+    if (R <= 256 && 256 % R == 0 && blockDim.x == 256) {      // W2[r, :] . dp2 over all 256 threads: thread (p, r) takes the channels c = p mod (256 / R)
+        const int np = 256 / R, r = threadIdx.x / np, p = threadIdx.x % np;      // consecutive threads read consecutive channels of one weight row
+        part[r * np + p] = se_dot(W2 + (size_t)r * C + p, (size_t)np, dp2 + p, np, (C - p + np - 1) / np);
+        __syncthreads();
+        if (threadIdx.x < R) {
+            const int rr = threadIdx.x;
+            float t = 0.f;
+            for (int q = 0; q < np; ++q) t += part[rr * np + q];
+            const float hp = hid_pre[(size_t)b * R + rr];
+            const float d = t * dswishf_(hp);
+            dhp[rr] = d;
+            sb[C + rr] = d;
+            sb[C + R + rr] = swishf_(hp);
+        }
+    } else {
+        for (int r = threadIdx.x; r < R; r += blockDim.x) {
+            float acc = 0.f;
+            for (int c = 0; c < C; ++c) acc += W2[(size_t)r * C + c] * dp2[c];
+            const float hp = hid_pre[(size_t)b * R + r];
+            const float d = acc * dswishf_(hp);
+            dhp[r] = d;
+            sb[C + r] = d;
+            sb[C + R + r] = swishf_(hp);
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += W1[(size_t)c * R + r] * dhp[r];
-        dgapT[(size_t)b * C + c] = acc * invT;
-    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dgapT[(size_t)b * C + c] = se_dot(W1 + (size_t)c * R, 1, dhp, 1, R) * invT;
 }
 // step 2: weight gradients as sums over the samples in a fixed order (no float atomics: the gradients repeat bit for bit).
 // workgroup = 64 parameters (lane) x 4 sample groups (wave w takes b = w, w+4, ...; 8 independent loads in flight), combined through LDS:
@@ -1581,7 +1617,7 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
 int launch_se_bwd(const float* dse, const float* gap, float invT, const float* W1, const float* W2,
                   const float* hid_pre, const float* se, float* dW1, float* db1, float* dW2, float* db2,
                   float* dgapT, float* scr, int B, int C, int R, hipStream_t s) {
-    hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), s, dse, gap, invT, W1, W2, hid_pre, se, scr, dgapT, C, R);
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (C + R + 256) * sizeof(float), s, dse, gap, invT, W1, W2, hid_pre, se, scr, dgapT, C, R);
     hipLaunchKernelGGL(se_wgrad_kernel, dim3((2 * C * R + C + R + 63) / 64), dim3(256), 0, s, scr, gap, invT, dW1, db1, dW2, db2, B, C, R);
     return LAUNCH_OK();
 }
