@@ -205,7 +205,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
                 q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
                 rstd[i] = rsqrtf(q * (1.f / K) + ea.ln_eps);
                 const int m = mw + 16 * i + c;
-                if (g == 0 && m < M && ea.ln_mean) { ea.ln_mean[m] = mean[i]; ea.ln_rstd[m] = rstd[i]; }
+                if (g == 0 && m < M && ea.ln_mean && blockIdx.y == 0) { ea.ln_mean[m] = mean[i]; ea.ln_rstd[m] = rstd[i]; }      // column splits redo the prologue; one of them writes
             }
         }
 #pragma unroll
@@ -434,7 +434,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
     // the prologue's transformed rows, for the backward pass: stored AFTER the column loop (the fragments are still in registers), so
     // that these stores do not sit in front of the loop's counted vmcnt waits and drain beside other workgroups' loops
     if constexpr (PRO != 0) {
-        if (ea.pro_out) {
+        if (ea.pro_out && blockIdx.y == 0) {
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
                 const int m = mw + 16 * i + c;
@@ -507,7 +507,6 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     if constexpr (is_16b_t<TC>::value && KT >= 8) {
 #define AS_PRO(MASK, PRO) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK, 0, PRO>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
         if (ea.ln_gamma) {           // LayerNorm prologue: the GEMMs that consume a LayerNorm output (FFN expand, QKV, conv-module expand)
-            if (gy != 1 && (ea.pro_out || ea.ln_mean)) { ishara_set_error("gemm_nt_as: prologue side outputs with split columns"); return -1; }
             switch (mask) {
                 case 0: AS_PRO(0, 1); break;
                 case AS_ACT | AS_PREOUT: AS_PRO(AS_ACT | AS_PREOUT, 1); break;
@@ -518,7 +517,6 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
             return hipGetLastError() == hipSuccess ? 0 : -2;
         }
         if (ea.pa_P) {               // per-sample affine prologue: the project GEMM of a Conv1DBlock
-            if (gy != 1 && ea.pro_out) { ishara_set_error("gemm_nt_as: prologue side outputs with split columns"); return -1; }
             switch (mask) {
                 case AS_RESID: AS_PRO(AS_RESID, 2); break;
                 case AS_RESID | AS_ROWSCALE: AS_PRO(AS_RESID | AS_ROWSCALE, 2); break;
@@ -579,9 +577,8 @@ bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int 
     if (!dt_is16(dtA) || dtM != dtA || dtC != dtA || (K != 256 && K != 512 && !(K == 1024 && dtA == DT_BF16)) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
     if (ldb % 64 != 0 || g_force_regstage) return false;
     const int BR = K == 256 ? 128 : (K == 512 ? 192 : 128), gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : (K == 512 ? 512 : 256);
-    // the launcher would split the columns: every split redoes the prologue on its rows — fine when nothing is written (inference),
-    // not when the transformed rows / statistics are side outputs
-    if (gx * 2 <= slots && (N / AS_NS) % 2 == 0 && N / 2 >= 128 && (ea.pro_out || ea.ln_mean)) return false;
+    // (when the launcher splits the columns every split redoes the prologue on its rows and the blockIdx.y == 0 split writes the side outputs)
+    (void)gx; (void)slots;
     const int mask = as_mask_of(ea);
     if (ea.ln_gamma) return mask == 0 || mask == (AS_ACT | AS_PREOUT) || mask == (AS_ACT | AS_PREOUT | AS_DROP) || mask == AS_QKV;
     if (ea.pa_P) return ea.T > 0 && ea.T % BR == 0 && (mask == AS_RESID || mask == (AS_RESID | AS_ROWSCALE));   // a workgroup's rows inside one sample

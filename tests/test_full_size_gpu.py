@@ -111,8 +111,8 @@ def test_project_conv_wgrad_per_sample_affine_matches_materialised_operand(model
     worst = 0.0
     worst_name = ""
     for name, shape, off, trainable in mb.entries:
-        if not trainable:
-            continue
+        if not trainable or name.endswith("/depthwise_conv/bias"):
+            continue        # (the Conformer conv's depthwise bias feeds a BatchNorm: its exact gradient is 0, what is computed is rounding residue)
         n = int(np.prod(shape))
         a, b_ = ga[off:off + n], gb[off:off + n]
         den = a.norm().item()
