@@ -821,7 +821,7 @@ size_t dwconv_fwd_scratch_floats(int B, int T, int C) { return (size_t)B * ((T +
 // `part`: scratch of dwconv_fwd_scratch_floats(B, T, C) floats for the deterministic statistics, or nullptr (then colsum /
 // colsq must be zero-filled by the caller and are accumulated with float atomics)
 int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const float* bias, void* y,
-                      float* colsum, float* colsq, float* part, int B, int T, int C, int k, int padl, hipStream_t s) {
+                      float* colsum, float* colsq, float* part, int B, int T, int C, int k, int padl, hipStream_t s, int* part_rows) {
     if (dwconv_check(C, k)) return -1;
     if (!colsum) part = nullptr;
     int P;
@@ -841,7 +841,8 @@ int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const flo
         else if (dt == DT_F16) DWK_LAUNCH(f16, (const f16*)x, w, bias, (f16*)y, (const f16*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0, part);
         else DWK_LAUNCH(float, (const float*)x, w, bias, (float*)y, (const float*)nullptr, colsum, colsq, B, T, C, k, padl, inop, (int)OUT_NONE, 0, part);
     }
-    if (part) hipLaunchKernelGGL(stats_reduce_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, P, colsum, colsq, B, C);
+    if (part && part_rows) *part_rows = P;          // the caller sums the partial rows itself (eca_fwd's inference form)
+    else if (part) hipLaunchKernelGGL(stats_reduce_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, P, colsum, colsq, B, C);
     return LAUNCH_OK();
 }
 
@@ -1142,18 +1143,35 @@ int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count,
 // =====================================================================================
 // ECA gate on [B,C] (one workgroup per sample)
 // =====================================================================================
+// inf.part != nullptr (inference): the kernel also does what two launches did before it — the sum of the depthwise conv's partial statistic
+// rows (the sample's channel sums over time) and the BatchNorm constants from the moving statistics (a = gamma * rsqrt(mv + eps),
+// b = beta - mm * a) — so a Conv1DBlock's forward is 4 launches instead of 6 (configs[4]: B = 1, every launch is ~9 us of latency)
+struct EcaInfer { const float* part = nullptr; int prows = 0; const float* mm = nullptr; const float* mv = nullptr; const float* gamma = nullptr; const float* beta = nullptr; float eps = 0.f; };
 __global__ __launch_bounds__(256) void eca_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ a, const float* __restrict__ bsh,
                                                       const float* __restrict__ w5, float invT, float* __restrict__ gn,
-                                                      float* __restrict__ sg, float* __restrict__ P, float* __restrict__ Q, int C, float* __restrict__ rs, DropSpec dp, int dp_fold) {
-    extern __shared__ float sh[];   // [C + 4]
+                                                      float* __restrict__ sg, float* __restrict__ P, float* __restrict__ Q, int C, float* __restrict__ rs, DropSpec dp, int dp_fold, EcaInfer inf) {
+    extern __shared__ float sh[];   // [C + 4] (+ [C] a, [C] b for the inference form)
+    float* al = sh + C + 4;
+    float* bl = al + C;
     const int b = blockIdx.x;
     for (int c = threadIdx.x; c < C + 4; c += blockDim.x) {
         const int cc = c - 2;
         float g = 0.f;
-        if (cc >= 0 && cc < C) { g = a[cc] * gap[(size_t)b * C + cc] * invT + bsh[cc]; gn[(size_t)b * C + cc] = g; }
+        if (cc >= 0 && cc < C) {
+            if (inf.part) {
+                const float* p = inf.part + ((size_t)b * inf.prows * 2) * C + cc;
+                float s0 = 0.f;
+                for (int r = 0; r < inf.prows; ++r) s0 += p[(size_t)(2 * r) * C];
+                const float aa = inf.gamma[cc] * rsqrtf(inf.mv[cc] + inf.eps), bb = inf.beta[cc] - inf.mm[cc] * aa;
+                al[cc] = aa; bl[cc] = bb;
+                g = aa * s0 * invT + bb;
+            } else g = a[cc] * gap[(size_t)b * C + cc] * invT + bsh[cc];
+            gn[(size_t)b * C + cc] = g;
+        }
         sh[c] = g;
     }
     __syncthreads();
+    if (inf.part) { a = al; bsh = bl; }
     const float w0 = w5[0], w1 = w5[1], w2 = w5[2], w3 = w5[3], w4 = w5[4];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float z = w0 * sh[c] + w1 * sh[c + 1] + w2 * sh[c + 2] + w3 * sh[c + 3] + w4 * sh[c + 4];
@@ -1174,7 +1192,14 @@ __global__ __launch_bounds__(256) void eca_fwd_kernel(const float* __restrict__ 
 
 int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
                    float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, float* rs, DropSpec dp, int dp_fold) {
-    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, gap, a, b, w5, invT, gn, sgate, P, Q, C, rs, dp, dp_fold);
+    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, gap, a, b, w5, invT, gn, sgate, P, Q, C, rs, dp, dp_fold, EcaInfer{});
+    return LAUNCH_OK();
+}
+int launch_eca_fwd_infer(const float* part, int prows, const float* mm, const float* mv, const float* gamma, const float* beta, float eps, const float* w5, float invT,
+                         float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s) {
+    EcaInfer inf; inf.part = part; inf.prows = prows; inf.mm = mm; inf.mv = mv; inf.gamma = gamma; inf.beta = beta; inf.eps = eps;
+    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (3 * C + 4) * sizeof(float), s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w5, invT, gn, sgate, P, Q, C,
+                       (float*)nullptr, DropSpec{0, 0, 1.f}, 0, inf);
     return LAUNCH_OK();
 }
 

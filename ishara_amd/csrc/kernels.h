@@ -114,7 +114,8 @@ enum : int { DWIN_NONE = 0, DWIN_SWISH = 1, DWIN_GLU = 2 };
 // ssum / ssq: per-sample channel sums of y and y^2 [B, C] (or nullptr).  `part`: scratch of dwconv_fwd_scratch_floats(B, T, C)
 // floats -> deterministic sums without atomics or zero fills; nullptr -> the caller zero-fills ssum / ssq, float atomics
 int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const float* bias, void* y,
-                      float* ssum, float* ssq, float* part, int B, int T, int C, int k, int padl, hipStream_t s);
+                      float* ssum, float* ssq, float* part, int B, int T, int C, int k, int padl, hipStream_t s, int* part_rows = nullptr);
+// part_rows != nullptr: the partial statistic rows stay unsummed in `part` ([B][rows][2][C]: sum | sum of squares), *part_rows = rows per sample
 size_t dwconv_fwd_scratch_floats(int B, int T, int C);
 // dx = d in(x) ; dw [k,C], dbias [C] accumulated (through `scratch` partial rows of
 // dwconv_bwd_scratch_floats(C,k) floats when given, else atomically).
@@ -141,6 +142,9 @@ int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count,
 int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
                    float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, float* rs = nullptr, DropSpec dp = {0, 0, 1.f}, int dp_fold = 0);
 // rs != nullptr: the kernel also draws the per-sample drop-path scale rs[b] (dp) and, with dp_fold, scales P and Q by it
+// inference form: the sample's channel sums come from the depthwise conv's partial rows, a / b from the BatchNorm's moving statistics
+int launch_eca_fwd_infer(const float* part, int prows, const float* mm, const float* mv, const float* gamma, const float* beta, float eps, const float* w5, float invT,
+                         float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s);
 // y = x*P[b,c] + Q[b,c] (+ resid)    (P,Q per sample) ; if Q == nullptr -> no offset
 int launch_sample_affine(int dt, const void* x, const float* P, const float* Q, const void* resid, void* y,
                          int B, int T, int C, hipStream_t s);

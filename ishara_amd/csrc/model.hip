@@ -523,7 +523,13 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     const int d = m->d, c = 2 * d, B = r.B, T = m->T, dt = m->dt;
     OpArgs no; EpiArgs e1;
     CK(gemm_fwd(m, cb.W1, x, dt, m->W(cb.z1), dt, r.M, OP_NONE, no, e1));
-    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s));
+    // inference: the partial statistic rows of the depthwise conv are summed, and the BatchNorm constants formed from the moving statistics,
+    // inside eca_fwd (4 launches per Conv1DBlock instead of 6: at B = 1 every launch is ~9 us of latency)
+    int prows = 0;
+    const bool infer_fused = !r.training && getenv("ISHARA_NO_INFER_FUSION") == nullptr;
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s,
+                                                                                          infer_fused ? &prows : nullptr));
+    if (!(infer_fused && prows > 0))
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(cb.ssum), m->Wf(cb.ssq), B, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
                           m->P(cb.bn.mm), m->P(cb.bn.mv), r.training, m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.bsh), c, m->s));
     // Drop-path (c5:82-83) on the branch: y = x + rs[b] * (h4 W2 + b2).  Where the fast kernels apply, rs[b] is folded into the per-sample
@@ -539,6 +545,10 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
                     gemm_tn_bias_rowscale_ok(dt, dt, dt, r.M, cb.W2.K, cb.W2.N, T);
         e2.rowscale_bias = cb.folded ? 1 : 0;
     }
+    if (infer_fused && prows > 0)
+        CKP(m, "eca_fwd", 0, 0, launch_eca_fwd_infer(m->Wf(m->slab), prows, m->P(cb.bn.mm), m->P(cb.bn.mv), m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, m->P(cb.eca), 1.f / T,
+                                                       m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s));
+    else
     CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s, ds.thr ? m->Wf(cb.rs) : nullptr, ds, cb.folded ? 1 : 0));
     // h4 = h2 * P[b] + Q[b] (BatchNorm + ECA gate [+ drop-path]) as a prologue of the project GEMM: h2 is read once, h4 is written from
     // the transformed fragments for the weight-gradient GEMM (training only); other shapes run the separate affine pass
@@ -611,7 +621,7 @@ int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
     CK(gemm_fwd(m, c.Wp1, x, dt, m->W(c.g), dt, r.M, OP_NONE, no, e0));
-    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), c.dwb >= 0 ? m->P(c.dwb) : nullptr, m->W(c.v), m->Wf(c.ssum), m->Wf(c.ssq), m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), c.dwb >= 0 ? m->P(c.dwb) : nullptr, m->W(c.v), r.training ? m->Wf(c.ssum) : nullptr, r.training ? m->Wf(c.ssq) : nullptr, m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));      // inference: no batch statistics
     const float var_corr = c.bn_unbiased && B * T > 1 ? (float)((double)B * T / ((double)B * T - 1.0)) : 1.f;
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), c.bn_eps, c.bn_keep,
                           m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s, var_corr));
@@ -648,6 +658,7 @@ extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float*
         CK(gemm_fwd(m, wp, m->W(m->stem_xb), dt, m->W(m->stem_h0), dt, r.M, OP_NONE, no, es));
     } else
         CK(gemm_fwd(m, m->stemW, x, DT_F32, m->W(m->stem_h0), dt, r.M, OP_NONE, no, es));
+    if (training)           // (inference: the BatchNorm uses its moving statistics, nothing reads the batch sums)
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, m->W(m->stem_h0), m->W(m->stem_h0), nullptr, nullptr, m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, T, d, m->s));
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(m->stem_ssum), m->Wf(m->stem_ssq), B, (float)B * T, m->P(m->stem_bn.gamma), m->P(m->stem_bn.beta), 1e-3f, 0.95f,
                           m->P(m->stem_bn.mm), m->P(m->stem_bn.mv), training, m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->stem_a), m->Wf(m->stem_bsh), d, m->s));
