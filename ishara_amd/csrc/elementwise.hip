@@ -360,6 +360,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
 // so every input element is loaded and activated once, there is no LDS tile and no barrier.
 // -------------------------------------------------------------------------------------
 #define DWR_SEG 32
+#define DWR_SEG_SMALL 8      // dwconv_reg8_kernel at B <= DW_SMALL_B
+#define DW_SMALL_B 8
 
 // raw 4-channel load (value v, GLU gate g) and the input transform, kept separate so that a K-group's loads can all be
 // issued before the first one is consumed
@@ -656,11 +658,11 @@ DEVI void dw8_raw(const T* __restrict__ x, int b, int tin, int Tn, int C, int Ci
 }
 template <typename T, int K, int INOP>
 __global__ __launch_bounds__(256) void dwconv_reg8_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                          T* __restrict__ y, int Tn, int C, int padl, float* __restrict__ part) {
+                                                          T* __restrict__ y, int Tn, int C, int padl, float* __restrict__ part, int seglen) {
     constexpr int inop = INOP;
     extern __shared__ float sred8[];            // [segments per workgroup][C/8][16]
     const int cg = C >> 3, spw = 256 / cg;
-    const int nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
+    const int nseg = (Tn + seglen - 1) / seglen;      // seglen: DWR_SEG, or DWR_SEG_SMALL for a handful of samples (more, shorter chains)
     const int cl = threadIdx.x % cg, sl = threadIdx.x / cg;
     const int seg = blockIdx.x * spw + sl, b = blockIdx.y;
     const bool live = seg < nseg;
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(256) void dwconv_reg8_kernel(const T* __restrict__ 
     for (int j = 0; j < K; ++j) { load4(w + (size_t)j * C + ch, *reinterpret_cast<float(*)[4]>(&wr[j][0])); load4(w + (size_t)j * C + ch + 4, *reinterpret_cast<float(*)[4]>(&wr[j][4])); }
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (bias) { load4(bias + ch, *reinterpret_cast<float(*)[4]>(&bv[0])); load4(bias + ch + 4, *reinterpret_cast<float(*)[4]>(&bv[4])); }
-    const int t0 = seg * DWR_SEG, tend = live ? min(Tn, t0 + DWR_SEG) : t0;
+    const int t0 = seg * seglen, tend = live ? min(Tn, t0 + seglen) : t0;
     auto xform = [&](float (&v)[8], const float (&g)[8]) {
         if (inop == DWIN_SWISH) {
 #pragma unroll
@@ -759,10 +761,13 @@ __global__ __launch_bounds__(256) void dwconv_reg8_kernel(const T* __restrict__ 
 static bool dw_reg8_ok(int dt, int C, int k) { return dt != DT_F32 && (k == 3 || k == 5) && C % 8 == 0 && C / 8 >= 32 && C / 8 <= 256 && 256 % (C / 8) == 0; }
 template <typename T>
 static int launch_dw_reg8(int k, const T* x, const float* w, const float* bias, T* y, int B, int Tn, int C, int padl, int inop, float* part, hipStream_t s) {
-    const int cg = C / 8, spw = 256 / cg, nseg = (Tn + DWR_SEG - 1) / DWR_SEG;
+    // a handful of samples (B = 1 inference): 8-step segments — four times the workgroups, a quarter of the dependent steps per thread
+    // (3 workgroups of 32-step chains took 17 us at T = 384)
+    const int seglen = B <= DW_SMALL_B ? DWR_SEG_SMALL : DWR_SEG;
+    const int cg = C / 8, spw = 256 / cg, nseg = (Tn + seglen - 1) / seglen;
     const dim3 grid((nseg + spw - 1) / spw, B);
     const size_t sh = (size_t)256 * 16 * sizeof(float);
-#define DW8(KK, OP) hipLaunchKernelGGL((dwconv_reg8_kernel<T, KK, OP>), grid, dim3(256), sh, s, x, w, bias, y, Tn, C, padl, part)
+#define DW8(KK, OP) hipLaunchKernelGGL((dwconv_reg8_kernel<T, KK, OP>), grid, dim3(256), sh, s, x, w, bias, y, Tn, C, padl, part, seglen)
 #define DW8K(OP) do { if (k == 3) DW8(3, OP); else DW8(5, OP); } while (0)
     if (inop == DWIN_SWISH) DW8K(DWIN_SWISH); else if (inop == DWIN_GLU) DW8K(DWIN_GLU); else DW8K(DWIN_NONE);
 #undef DW8K
@@ -816,7 +821,10 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restri
         else if (k <= 15) hipLaunchKernelGGL((dwconv_kernel<TT, 0, 15>), grid, dim3(256), 0, s, __VA_ARGS__);   /* K = 15 unrolled: 86 vs 78 us */ \
         else hipLaunchKernelGGL((dwconv_kernel<TT, 0, DW_MAXK>), grid, dim3(256), 0, s, __VA_ARGS__);            \
     } while (0)
-size_t dwconv_fwd_scratch_floats(int B, int T, int C) { return (size_t)B * ((T + DWR_SEG - 1) / DWR_SEG) * 2 * C; }   // the most partial rows any forward kernel writes per sample (one per 32-step segment)
+size_t dwconv_fwd_scratch_floats(int B, int T, int C) {
+    const size_t big = (size_t)B * ((T + DWR_SEG - 1) / DWR_SEG), small = (size_t)(B < DW_SMALL_B ? B : DW_SMALL_B) * ((T + DWR_SEG_SMALL - 1) / DWR_SEG_SMALL);
+    return (big > small ? big : small) * 2 * C;
+}   // the most partial rows any forward kernel writes per sample (one per 32-step segment)
 
 // `part`: scratch of dwconv_fwd_scratch_floats(B, T, C) floats for the deterministic statistics, or nullptr (then colsum /
 // colsq must be zero-filled by the caller and are accumulated with float atomics)
