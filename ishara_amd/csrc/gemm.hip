@@ -1983,7 +1983,8 @@ int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt,
 
 // xb[M, Kp] (bf16) = x[M, F] (f32) zero padded: the stem's input rows as an MFMA operand (the f32-A GEMM kernels round the
 // same way while staging; done once here, the stem Dense and its wgrad run on the bf16 fast paths with K = Kp)
-__global__ __launch_bounds__(256) void pack_rows_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ xb, int M, int F, int Kp) {
+template <typename TM>
+__global__ __launch_bounds__(256) void pack_rows_bf16_kernel(const float* __restrict__ x, TM* __restrict__ xb, int M, int F, int Kp) {
     const int cpr = Kp >> 3;                                   // 16-byte output chunks per row
     const size_t total = (size_t)M * cpr;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -1993,12 +1994,14 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(const float* __rest
         const float* src = x + row * F + c0;
         if (c0 + 4 <= F) { const float4 a = *reinterpret_cast<const float4*>(src); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
         if (c0 + 8 <= F) { const float4 a = *reinterpret_cast<const float4*>(src + 4); v[4] = a.x; v[5] = a.y; v[6] = a.z; v[7] = a.w; }
-        *reinterpret_cast<u32x4*>(xb + row * Kp + c0) = pack_chunk<bf16, 8>(v);
+        *reinterpret_cast<u32x4*>(xb + row * Kp + c0) = pack_chunk<TM, 8>(v);
     }
 }
-int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s) {
+int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s, int dt) {
     if (F % 4 != 0 || Kp % 8 != 0 || Kp < F || ((uintptr_t)x) % 16 != 0) { ishara_set_error("pack_rows_bf16: F=%d Kp=%d unsupported", F, Kp); return -1; }
-    hipLaunchKernelGGL(pack_rows_bf16_kernel, dim3(2048), dim3(256), 0, s, x, (bf16*)xb, M, F, Kp);
+    const int grid = (int)std::min<size_t>(2048, ((size_t)M * (Kp >> 3) + 255) / 256);
+    if (dt == DT_F16) hipLaunchKernelGGL(pack_rows_bf16_kernel<f16>, dim3(grid), dim3(256), 0, s, x, (f16*)xb, M, F, Kp);
+    else hipLaunchKernelGGL(pack_rows_bf16_kernel<bf16>, dim3(grid), dim3(256), 0, s, x, (bf16*)xb, M, F, Kp);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -83,7 +83,7 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
                    const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0, int nb_valid = 0,
                    const float* bias_rowscale = nullptr, int bias_T = 0, TnDefer* defer = nullptr, const TnPsa* psa = nullptr);   // bias_rowscale: dbias = sum_m bias_rowscale[m / bias_T] * B[m,:] (gemm_tn_bias_rowscale_ok shapes only); ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
 // xb[M, Kp] (bf16) = x[M, F] (f32), zero padded to Kp columns (F % 4 == 0, Kp % 8 == 0)
-int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s);
+int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s, int dt = DT_BF16);   // dt: DT_BF16 or DT_F16 (the fp16 inference path)
 
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
 // the kernel also takes ea's prologue (ln_* / pa_*): bf16 output, K in {256, 512}, whole 16-row tiles inside one sample for pa_*

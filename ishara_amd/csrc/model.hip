@@ -210,7 +210,7 @@ static void plan_workspace(ishara_model* m) {
     m->cur = 0;
     // ---- shadows first (one contiguous arena that sync_weights zero-fills)
     m->shadow_begin = m->cur;
-    m->stem_kp = (m->dt == DT_BF16 && m->F <= 512) ? (m->F <= 256 ? 256 : 512) : 0;
+    m->stem_kp = (dt_is16(m->dt) && m->F <= 512) ? (m->F <= 256 ? 256 : 512) : 0;      // fp16 (inference) too: the stem Dense on the A-stationary kernel
     plan_shadow(m, m->stemW, m->stem_kp);
     for (auto& cb : m->convs) { plan_shadow(m, cb.W1); plan_shadow(m, cb.W2); }
     // FFN/MHSA shadows are planned with their activations below; keep the arena contiguous by
@@ -653,7 +653,7 @@ extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float*
     // ---- stem: Dense(no bias) + PE, BatchNorm(momentum .95)  (c7:13-17)
     EpiArgs es; es.addtab = m->Wf(m->pe); es.tab_period = T;
     if (m->stem_kp) {       // bf16: pack the input rows once, then the Dense (and its wgrad) run on the bf16 fast paths with K = stem_kp
-        CKP(m, "pack_rows_bf16", (double)r.M * (m->F * 4.0 + m->stem_kp * 2.0), 0, launch_pack_rows_bf16(x, m->W(m->stem_xb), r.M, m->F, m->stem_kp, m->s));
+        CKP(m, "pack_rows_bf16", (double)r.M * (m->F * 4.0 + m->stem_kp * 2.0), 0, launch_pack_rows_bf16(x, m->W(m->stem_xb), r.M, m->F, m->stem_kp, m->s, dt));
         DenseW wp = m->stemW; wp.K = m->stem_kp;
         CK(gemm_fwd(m, wp, m->W(m->stem_xb), dt, m->W(m->stem_h0), dt, r.M, OP_NONE, no, es));
     } else
