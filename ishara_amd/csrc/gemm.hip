@@ -1997,6 +1997,51 @@ __global__ __launch_bounds__(256) void pack_rows_bf16_kernel(const float* __rest
         *reinterpret_cast<u32x4*>(xb + row * Kp + c0) = pack_chunk<TM, 8>(v);
     }
 }
+template <typename TM>
+__global__ __launch_bounds__(256) void dense_narrow_kernel(const TM* __restrict__ A, const TM* __restrict__ Wt, int ldt, const float* __restrict__ bias,
+                                                           float* __restrict__ C, int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int m0 = (blockIdx.x * 4 + wid) * 4;                  // this wave's 4 rows
+    const int n = min(lane, N - 1);
+    const TM* wrow = Wt + (size_t)n * ldt;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int mr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mr[r] = min(m0 + r, M - 1);
+    for (int k = 0; k < K; k += 32) {                            // 4 weight chunks and 16 operand chunks (wave-uniform addresses) in flight
+        u32x4 w[4], a[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = *reinterpret_cast<const u32x4*>(wrow + k + 8 * u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r][u] = *reinterpret_cast<const u32x4*>(A + (size_t)mr[r] * K + k + 8 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            typedef __attribute__((ext_vector_type(8))) TM v8;
+            const v8 wv = __builtin_bit_cast(v8, w[u]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const v8 av = __builtin_bit_cast(v8, a[r][u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r] += (float)av[e] * (float)wv[e];
+            }
+        }
+    }
+    if (lane < N) {
+        const float b = bias ? bias[lane] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (m0 + r < M) C[(size_t)(m0 + r) * N + lane] = acc[r] + b;
+    }
+}
+int launch_dense_narrow(int dt, const void* A, const void* Wt, int ldt, const float* bias, float* C, int M, int N, int K, hipStream_t s) {
+    if (!dt_is16(dt) || N < 1 || N > 64 || K % 32 != 0 || ldt % 8 != 0 || ((uintptr_t)A) % 16 != 0 || ((uintptr_t)Wt) % 16 != 0) { ishara_set_error("dense_narrow: N=%d K=%d unsupported", N, K); return -1; }
+    const dim3 grid((M + 15) / 16);
+    if (dt == DT_F16) hipLaunchKernelGGL(dense_narrow_kernel<f16>, grid, dim3(256), 0, s, (const f16*)A, (const f16*)Wt, ldt, bias, C, M, N, K);
+    else hipLaunchKernelGGL(dense_narrow_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)A, (const bf16*)Wt, ldt, bias, C, M, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s, int dt) {
     if (F % 4 != 0 || Kp % 8 != 0 || Kp < F || ((uintptr_t)x) % 16 != 0) { ishara_set_error("pack_rows_bf16: F=%d Kp=%d unsupported", F, Kp); return -1; }
     const int grid = (int)std::min<size_t>(2048, ((size_t)M * (Kp >> 3) + 255) / 256);

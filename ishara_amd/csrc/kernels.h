@@ -82,6 +82,10 @@ int launch_gemm_tn(int dtA, int dtB, int dtM, int opA, int opB, const void* A, c
                    float* out, float* dbias, float* slab, int M, int Ka, int Nb,
                    const OpArgs& oa, const OpArgs& ob, hipStream_t s, int ka_valid = 0, int nb_valid = 0,
                    const float* bias_rowscale = nullptr, int bias_T = 0, TnDefer* defer = nullptr, const TnPsa* psa = nullptr);   // bias_rowscale: dbias = sum_m bias_rowscale[m / bias_T] * B[m,:] (gemm_tn_bias_rowscale_ok shapes only); ka_valid < Ka: A columns [ka_valid, Ka) are zero padding, out has ka_valid rows; nb_valid < Nb: same for B / out columns / dbias
+// C[M, N] (f32) = A[M, K] (bf16 / fp16) . Wt[N, K]^T + bias for a NARROW output (N <= 64: the classifier) and few rows: a lane per output
+// column, four rows per wave, the weight row streamed from L2 — the 64 x 128 tile kernel needs 37 us for M = 384, N = 60, K = 512
+// (6 workgroups); this one is for the latency of a B = 1 clip, not for throughput (M <= 4096)
+int launch_dense_narrow(int dt, const void* A, const void* Wt, int ldt, const float* bias, float* C, int M, int N, int K, hipStream_t s);
 // xb[M, Kp] (bf16) = x[M, F] (f32), zero padded to Kp columns (F % 4 == 0, Kp % 8 == 0)
 int launch_pack_rows_bf16(const float* x, void* xb, int M, int F, int Kp, hipStream_t s, int dt = DT_BF16);   // dt: DT_BF16 or DT_F16 (the fp16 inference path)
 

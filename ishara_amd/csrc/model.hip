@@ -684,6 +684,9 @@ extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float*
     EpiArgs et; et.act = ACT_RELU; et.drop = dspec(r, m->head_site, m->cfg.head_dropout);
     CK(gemm_fwd(m, m->topW, h, dt, m->W(m->head_hh), dt, r.M, OP_NONE, no, et));
     EpiArgs ec;
+    if (dt_is16(dt) && r.M <= 4096 && m->C <= 64 && m->clsW.K % 32 == 0 && getenv("ISHARA_NO_INFER_FUSION") == nullptr)       // few rows: the narrow-output kernel (latency of a clip)
+        CKP(m, "dense_narrow", 0, 2.0 * r.M * m->C * m->clsW.K, launch_dense_narrow(dt, m->W(m->head_hh), m->ws + m->clsW.wt, m->clsW.ldt, m->clsW.b >= 0 ? m->P(m->clsW.b) : nullptr, logits, r.M, m->C, m->clsW.K, m->s));
+    else
     CK(gemm_fwd(m, m->clsW, m->W(m->head_hh), dt, logits, DT_F32, r.M, OP_NONE, no, ec));
     m->lastB = B; m->last_training = training; m->last_seed = seed; m->last_x = x;
     return 0;
