@@ -283,7 +283,13 @@ __global__ __launch_bounds__(256) void greedy_decode_kernel(const float* __restr
     for (int t = tid; t < Tn; t += blockDim.x) {
         float best = lg[(size_t)t * C];
         int bi = 0;
-        for (int c = 1; c < C; ++c) { const float v = lg[(size_t)t * C + c]; if (v > best) { best = v; bi = c; } }
+        for (int c0 = 0; c0 < C; c0 += 16) {       // 16 loads in flight, then the (ordered: first max wins) comparisons
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = lg[(size_t)t * C + min(c0 + u, C - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (c0 + u < C && v[u] > best) { best = v[u]; bi = c0 + u; }
+        }
         am[t] = bi;
     }
     if (tid == 0) s_base = 0;
