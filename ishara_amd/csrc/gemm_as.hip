@@ -48,7 +48,8 @@ extern int g_force_regstage;
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
 
 #define AS_NS 32            // output columns (staged weight rows) per step
-#define AS_SMALL_M 1536     // K = 512: at or below this many rows the workgroups take 64 rows instead of 192 (latency of a B = 1 clip)
+#define AS_SMALL_M 1536     // K <= 512: at or below this many rows the workgroups take 64 rows instead of 128 / 192, and the columns are split
+                            // down to one 32-column step per workgroup (latency of a B = 1 clip: 22.6 -> ~7 us per K = 512 GEMM)
 #define AS_MAXN 1024
 
 typedef __attribute__((ext_vector_type(4))) uint32_t as_u32x4;
@@ -462,7 +463,8 @@ __global__ __launch_bounds__(KT <= 16 ? 256 : 512, KT <= 8 ? 3 : (KT <= 16 ? 2 :
     // bias -> LDS (visible after the first barrier of the step loop)
     for (int n = threadIdx.x; n < N; n += (int)blockDim.x) bias_s[n] = ea.bias ? ea.bias[n] : 0.f;
     if constexpr (KT <= 8) {
-        as_pass<TC, KT, MASK, 2, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
+        if (M <= AS_SMALL_M) as_pass<TC, KT, MASK, 1, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 64);      // a clip's worth of rows: 64-row workgroups (see below)
+        else as_pass<TC, KT, MASK, 2, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
     } else if constexpr (KT >= 32) {
         // K = 1024 (config #4's 2d = 1024 operands): 16 rows per wave (the fragments of ONE row tile already take 128 VGPRs), EIGHT
         // waves = 128-row workgroups around a ring of 2 x 64 KB -> one workgroup per CU, two waves per SIMD.  Half the rows per staged
@@ -501,12 +503,14 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
 #define AS_LAUNCH(MASK) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
 template <typename TC, int KT>
 static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea, hipStream_t s) {
-    const int BR = KT <= 8 ? 128 : (KT <= 16 ? (M <= AS_SMALL_M ? 64 : 192) : 128);     // rows per workgroup
+    const int BR = KT <= 8 ? (M <= AS_SMALL_M ? 64 : 128) : (KT <= 16 ? (M <= AS_SMALL_M ? 64 : 192) : 128);     // rows per workgroup
     // few rows (config #4 at small batches: M / 192 = 171 workgroups for 512 slots): split the columns 2- or 4-way; every
     // workgroup then loads its A rows again, which is cheap exactly when M is small
     const int gx = (M + BR - 1) / BR, slots = KT <= 8 ? 768 : (KT <= 16 ? 512 : 256);
     int gy = 1;
-    while (gy < 4 && gx * gy * 2 <= slots && (N / AS_NS) % (gy * 2) == 0 && N / (gy * 2) >= 128) gy *= 2;
+    // (a clip's worth of rows: up to 8 splits of at least 64 columns — what counts there is the number of sequential column steps of one workgroup)
+    const int max_gy = M <= AS_SMALL_M ? 16 : 4, min_cols = M <= AS_SMALL_M ? 32 : 128;
+    while (gy < max_gy && gx * gy * 2 <= slots && (N / AS_NS) % (gy * 2) == 0 && N / (gy * 2) >= min_cols) gy *= 2;
     const dim3 grid(gx, gy), block(KT <= 16 ? 256 : 512);
     const int mask = as_mask_of(ea);
     if constexpr (is_16b_t<TC>::value && KT >= 8) {
@@ -581,7 +585,7 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
 bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
     if (!dt_is16(dtA) || dtM != dtA || dtC != dtA || (K != 256 && K != 512 && !(K == 1024 && dtA == DT_BF16)) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
     if (ldb % 64 != 0 || g_force_regstage) return false;
-    const int BR = K == 256 ? 128 : (K == 512 ? (M <= AS_SMALL_M ? 64 : 192) : 128), gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : (K == 512 ? 512 : 256);
+    const int BR = K == 256 ? (M <= AS_SMALL_M ? 64 : 128) : (K == 512 ? (M <= AS_SMALL_M ? 64 : 192) : 128), gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : (K == 512 ? 512 : 256);
     // (when the launcher splits the columns every split redoes the prologue on its rows and the blockIdx.y == 0 split writes the side outputs)
     (void)gx; (void)slots;
     const int mask = as_mask_of(ea);
