@@ -1155,7 +1155,7 @@ int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count,
 // rows (the sample's channel sums over time) and the BatchNorm constants from the moving statistics (a = gamma * rsqrt(mv + eps),
 // b = beta - mm * a) — so a Conv1DBlock's forward is 4 launches instead of 6 (configs[4]: B = 1, every launch is ~9 us of latency)
 struct EcaInfer { const float* part = nullptr; int prows = 0; const float* mm = nullptr; const float* mv = nullptr; const float* gamma = nullptr; const float* beta = nullptr; float eps = 0.f; };
-__global__ __launch_bounds__(256) void eca_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ a, const float* __restrict__ bsh,
+__global__ __launch_bounds__(1024) void eca_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ a, const float* __restrict__ bsh,
                                                       const float* __restrict__ w5, float invT, float* __restrict__ gn,
                                                       float* __restrict__ sg, float* __restrict__ P, float* __restrict__ Q, int C, float* __restrict__ rs, DropSpec dp, int dp_fold, EcaInfer inf) {
     extern __shared__ float sh[];   // [C + 4] (+ [C] a, [C] b for the inference form)
@@ -1206,7 +1206,8 @@ int launch_eca_fwd(const float* gap, const float* a, const float* b, const float
 int launch_eca_fwd_infer(const float* part, int prows, const float* mm, const float* mv, const float* gamma, const float* beta, float eps, const float* w5, float invT,
                          float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s) {
     EcaInfer inf; inf.part = part; inf.prows = prows; inf.mm = mm; inf.mv = mv; inf.gamma = gamma; inf.beta = beta; inf.eps = eps;
-    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (3 * C + 4) * sizeof(float), s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w5, invT, gn, sgate, P, Q, C,
+    const int threads = B <= 8 ? (C + 4 > 512 ? 1024 : 512) : 256;      // a clip or a few: a thread per channel (one workgroup per sample is all the parallelism there is)
+    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(threads), (3 * C + 4) * sizeof(float), s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, w5, invT, gn, sgate, P, Q, C,
                        (float*)nullptr, DropSpec{0, 0, 1.f}, 0, inf);
     return LAUNCH_OK();
 }

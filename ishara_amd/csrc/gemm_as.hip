@@ -259,7 +259,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
     // per-lane base offsets of the [M, N] operands (rows clamped: out-of-range rows load row M-1 and store nothing)
     size_t eoff[RT];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) eoff[i] = (size_t)mrow[i] * N + GW * g;
+    for (int i = 0; i < RT; ++i) eoff[i] = (size_t)mrow[i] * (ea.ldc ? ea.ldc : N) + GW * g;
     const TC* resid = reinterpret_cast<const TC*>(ea.resid);
     const TC* aux = reinterpret_cast<const TC*>(ea.aux);
 
@@ -349,6 +349,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             const int n = n0 + 4 * GW * q + GW * g;
+            if (ea.n_valid && n >= ea.n_valid) continue;      // padding columns of a narrow output
             float bias[GW];
 #pragma unroll
             for (int h = 0; h < GW / 4; ++h) {
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(KT <= 16 ? 256 : 512, KT <= 8 ? 3 : (KT <= 16 ? 2 :
     __shared__ __attribute__((aligned(16))) char smem[R * STAGE + AS_MAXN * 4];
     float* bias_s = reinterpret_cast<float*>(smem + R * STAGE);
     // bias -> LDS (visible after the first barrier of the step loop)
-    for (int n = threadIdx.x; n < N; n += (int)blockDim.x) bias_s[n] = ea.bias ? ea.bias[n] : 0.f;
+    for (int n = threadIdx.x; n < N; n += (int)blockDim.x) bias_s[n] = (ea.bias && (!ea.n_valid || n < ea.n_valid)) ? ea.bias[n] : 0.f;
     if constexpr (KT <= 8) {
         if (M <= AS_SMALL_M) as_pass<TC, KT, MASK, 1, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 64);      // a clip's worth of rows: 64-row workgroups (see below)
         else as_pass<TC, KT, MASK, 2, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);

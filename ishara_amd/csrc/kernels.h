@@ -49,6 +49,9 @@ struct EpiArgs {
     const float* pa_Q = nullptr;
     void* pro_out = nullptr;          // A' rows [M, K] in the operand type (null: not needed, inference)
     int head_major = 1;               // 1: cols = h*3dh + {q,k,v}*dh + i (TF path); 0: {q,k,v}*d + h*dh + i (torch twin)
+    // A-stationary kernel only: C rows are ldc elements apart (0: N) and only the columns below n_valid are stored (0: all) — a 60-column
+    // classifier runs as N = 64 over the zero-padded weight shadow (no residual / act' operands with these)
+    int ldc = 0, n_valid = 0;
 };
 
 // C[M,N] = epi( op(A)[M,K] . Bt[N,K]^T ).  Bt is a padded weight shadow: rows padded to

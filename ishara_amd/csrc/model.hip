@@ -684,7 +684,11 @@ extern "C" int ishara_forward(ishara_model* m, const float* x, int32_t B, float*
     EpiArgs et; et.act = ACT_RELU; et.drop = dspec(r, m->head_site, m->cfg.head_dropout);
     CK(gemm_fwd(m, m->topW, h, dt, m->W(m->head_hh), dt, r.M, OP_NONE, no, et));
     EpiArgs ec;
-    if (dt_is16(dt) && r.M <= 4096 && m->C <= 64 && m->clsW.K % 32 == 0 && getenv("ISHARA_NO_INFER_FUSION") == nullptr)       // few rows: the narrow-output kernel (latency of a clip)
+    if (dt_is16(dt) && r.M <= 1536 && m->C <= 64 && m->C % 4 == 0 && (m->clsW.K == 256 || m->clsW.K == 512) && !g_force_regstage && getenv("ISHARA_NO_INFER_FUSION") == nullptr) {
+        // a clip's worth of rows: the A-stationary MFMA kernel over the zero-padded weight shadow (N = 64), storing the real columns only
+        ec.bias = m->clsW.b >= 0 ? m->P(m->clsW.b) : nullptr; ec.ldc = m->C; ec.n_valid = m->C;
+        CKP(m, "classifier(as)", 0, 2.0 * r.M * m->C * m->clsW.K, launch_gemm_nt(dt, dt, DT_F32, OP_NONE, m->W(m->head_hh), m->ws + m->clsW.wt, logits, r.M, 64, m->clsW.K, m->clsW.ldt, no, ec, m->s));
+    } else if (dt_is16(dt) && r.M <= 4096 && m->C <= 64 && m->clsW.K % 32 == 0 && getenv("ISHARA_NO_INFER_FUSION") == nullptr)       // few rows: the narrow-output kernel (latency of a clip)
         CKP(m, "dense_narrow", 0, 2.0 * r.M * m->C * m->clsW.K, launch_dense_narrow(dt, m->W(m->head_hh), m->ws + m->clsW.wt, m->clsW.ldt, m->clsW.b >= 0 ? m->P(m->clsW.b) : nullptr, logits, r.M, m->C, m->clsW.K, m->s));
     else
     CK(gemm_fwd(m, m->clsW, m->W(m->head_hh), dt, logits, DT_F32, r.M, OP_NONE, no, ec));
