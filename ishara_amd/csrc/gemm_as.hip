@@ -50,6 +50,8 @@ bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs&
 #define AS_NS 32            // output columns (staged weight rows) per step
 #define AS_SMALL_M 1536     // K <= 512: at or below this many rows the workgroups take 64 rows instead of 128 / 192, and the columns are split
                             // down to one 32-column step per workgroup (latency of a B = 1 clip: 22.6 -> ~7 us per K = 512 GEMM)
+#define AS_MID_M_K512 32768 // K = 512 only: up to this many rows (<= 512 workgroups of 64 rows = one round at 2 per CU) the 64-row form also wins on
+                            // load balance — M = 32768 gives 171 workgroups of 192 rows x 2 column halves for 512 slots (configs[3]: 46.8 -> 44.8 ms/step)
 #define AS_MAXN 1024
 
 typedef __attribute__((ext_vector_type(4))) uint32_t as_u32x4;
@@ -471,8 +473,8 @@ __global__ __launch_bounds__(KT <= 16 ? 256 : 512, KT <= 8 ? 3 : (KT <= 16 ? 2 :
         // waves = 128-row workgroups around a ring of 2 x 64 KB -> one workgroup per CU, two waves per SIMD.  Half the rows per staged
         // weight byte of the K <= 512 variants, so the LDS fragment reads bound it near half the MFMA peak.
         as_pass<TC, KT, MASK, 1, DBG, PRO, 8>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 128);
-    } else if (M <= AS_SMALL_M) {
-        // few rows (B = 1 inference: M = T): 64-row workgroups, one 16-row tile per wave — three times the workgroups of the 192-row
+    } else if (M <= AS_MID_M_K512) {
+        // few rows (B = 1 inference: M = T; and M up to one round of 64-row workgroups): 64-row workgroups, one 16-row tile per wave — three times the workgroups of the 192-row
         // form and one pass instead of two sequential ones; the chip is empty either way, what counts is the latency of one workgroup
         as_pass<TC, KT, MASK, 1, DBG, PRO>(A, Bt, C, M, N, ldb, ea, smem, bias_s, blockIdx.x * 64);
     } else {
@@ -504,7 +506,7 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
 #define AS_LAUNCH(MASK) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
 template <typename TC, int KT>
 static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea, hipStream_t s) {
-    const int BR = KT <= 8 ? (M <= AS_SMALL_M ? 64 : 128) : (KT <= 16 ? (M <= AS_SMALL_M ? 64 : 192) : 128);     // rows per workgroup
+    const int BR = KT <= 8 ? (M <= AS_SMALL_M ? 64 : 128) : (KT <= 16 ? (M <= AS_MID_M_K512 ? 64 : 192) : 128);     // rows per workgroup
     // few rows (config #4 at small batches: M / 192 = 171 workgroups for 512 slots): split the columns 2- or 4-way; every
     // workgroup then loads its A rows again, which is cheap exactly when M is small
     const int gx = (M + BR - 1) / BR, slots = KT <= 8 ? 768 : (KT <= 16 ? 512 : 256);
@@ -586,7 +588,7 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
 bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int ldb, const EpiArgs& ea) {
     if (!dt_is16(dtA) || dtM != dtA || dtC != dtA || (K != 256 && K != 512 && !(K == 1024 && dtA == DT_BF16)) || !gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return false;
     if (ldb % 64 != 0 || g_force_regstage) return false;
-    const int BR = K == 256 ? (M <= AS_SMALL_M ? 64 : 128) : (K == 512 ? (M <= AS_SMALL_M ? 64 : 192) : 128), gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : (K == 512 ? 512 : 256);
+    const int BR = K == 256 ? (M <= AS_SMALL_M ? 64 : 128) : (K == 512 ? (M <= AS_MID_M_K512 ? 64 : 192) : 128), gx = (M + BR - 1) / BR, slots = K == 256 ? 768 : (K == 512 ? 512 : 256);
     // (when the launcher splits the columns every split redoes the prologue on its rows and the blockIdx.y == 0 split writes the side outputs)
     (void)gx; (void)slots;
     const int mask = as_mask_of(ea);
