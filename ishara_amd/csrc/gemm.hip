@@ -1944,7 +1944,10 @@ template <typename TM>
 __global__ void make_shadow_batched_kernel(const ShadowDesc* __restrict__ tab, int ntab) {
     __shared__ float tile[32][33];
     int wi = 0;
-    while (wi + 1 < ntab && (int)blockIdx.x >= tab[wi + 1].tile0) ++wi;
+    for (int hi = ntab; hi - wi > 1;) {       // the weight this tile belongs to: binary search over the descriptors' first tiles (a linear walk
+        const int mid = (wi + hi) >> 1;       // was up to ntab dependent loads per block: 0.7 ms per step for configs[3]'s 88 M parameters)
+        if ((int)blockIdx.x >= tab[mid].tile0) wi = mid; else hi = mid;
+    }
     const ShadowDesc d = tab[wi];
     const int lt = blockIdx.x - d.tile0;
     const int k0 = (lt / d.tiles_n) * 32, n0 = (lt % d.tiles_n) * 32;
