@@ -28,3 +28,11 @@ def test_config2_train_step_vs_oracle(dtype, dropout):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_config4_train_step_vs_oracle(dtype):
     check_train_step(CFG4, dtype, 0.2, "config4_B2", bf16_tol=CFG4_BF16_TOL, check_decode=True)
+
+
+def test_config2_b64_train_step_vs_oracle():
+    """configs[1]'s model at B = 64 against the fp64 oracle: the batch at which the project conv's weight-gradient GEMM (gemm.hip TnPsa) folds TWO
+    samples per M-split — sample boundaries inside the kernel's step loop, parked accumulators, the per-sample statistics of dh4 — and the
+    forward GEMM prologues run with split columns.  (B = 2 above exercises one sample per split; tests/test_full_size_gpu.py compares the two
+    HIP routes with each other at this batch.)  bf16, dropout on; ~20 s of oracle time."""
+    check_train_step(dict(CFG2, B=64), "bf16", 0.2, "config2_B64")
