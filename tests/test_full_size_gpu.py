@@ -121,3 +121,44 @@ def test_project_conv_wgrad_per_sample_affine_matches_materialised_operand(model
             if e > worst:
                 worst, worst_name = e, name
     assert worst <= 6e-2, f"worst per-parameter rel-L2 {worst} ({worst_name})"
+
+
+def test_project_conv_wgrad_psa_config4_shape():
+    """The same two-route comparison for configs[3]'s shapes (d512: the project conv is K = 1024 -> N = 512, 32 output tiles, T = 512 = 16
+    stages per sample, two samples per M-split at B = 16; the finalize kernel works on four 256-channel chunks per sample)."""
+    import os
+    kw = dict(dim=512, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, kernel_sizes=[11, 5, 3], num_conv_per_block=3,
+              num_heads=8, expansion_factor=2, transformer_kernel_size=15, input_shape=(512, 224))
+    b = 16
+    g = np.random.default_rng(21)
+    x = torch.from_numpy(g.standard_normal((b, 512, 224)).astype(np.float32)).cuda()
+    y = np.full((b, 64), 59, np.int64)
+    for i in range(b):
+        n = int(g.integers(8, 32))
+        y[i, :n] = g.integers(0, 59, n)
+    y = torch.from_numpy(y).cuda()
+    mb = get_model(**kw, dropout_rate=0.2, dtype="bf16", max_batch=b, seed=0)
+    os.environ["ISHARA_NO_PSA"] = "1"
+    try:
+        ma = get_model(**kw, dropout_rate=0.2, dtype="bf16", max_batch=b, seed=0)
+    finally:
+        del os.environ["ISHARA_NO_PSA"]
+    ma.set_weights(mb.get_weights())
+    lb, lgb = mb.loss_and_gradients(x, y, seed=5); gb = mb.grads.clone(); lgb = lgb.clone()
+    la, lga = ma.loss_and_gradients(x, y, seed=5); ga = ma.grads.clone()
+    assert torch.equal(lga, lgb) and float(la.item()) == float(lb.item())
+    assert torch.isfinite(gb).all()
+    rel = ((ga - gb).norm() / ga.norm()).item()
+    assert rel <= 2e-2, f"flat gradient rel-L2 between the two routes {rel}"
+    worst, worst_name = 0.0, ""
+    for name, shape, off, trainable in mb.entries:
+        if not trainable or name.endswith("/depthwise_conv/bias"):
+            continue
+        n = int(np.prod(shape))
+        a, b_ = ga[off:off + n], gb[off:off + n]
+        den = a.norm().item()
+        if den > 0:
+            e = (a - b_).norm().item() / den
+            if e > worst:
+                worst, worst_name = e, name
+    assert worst <= 6e-2, f"worst per-parameter rel-L2 {worst} ({worst_name})"
