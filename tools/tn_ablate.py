@@ -5,7 +5,8 @@ sys.path.insert(0, ".")
 from ishara_amd import _lib
 lib = _lib.load()
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for (M, K, N) in [(98304, 256, 512), (98304, 512, 256), (98304, 256, 768), (98304, 256, 256)]:
+SHAPES = [(98304, 256, 512), (98304, 512, 256), (98304, 256, 768), (98304, 256, 256)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for (M, K, N) in SHAPES:
     x = torch.randn(M, K, device="cuda").bfloat16(); dy = torch.randn(M, N, device="cuda").bfloat16()
     W = torch.randn(K, N, device="cuda") / K ** 0.5
     dW = torch.zeros(K, N, device="cuda"); db = torch.zeros(N, device="cuda")
