@@ -212,8 +212,8 @@ def run_training(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5], help="BASELINE.json config number (1-based): 2 = configs[1] (the metric's), 4 = d512 6+6 T512, 5 = B=1 inference latency")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (weak scaling); 0 = the config's")
     ap.add_argument("--dtype", default=None)
