@@ -88,11 +88,17 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, flat, enc):
         ctx.enc = enc
-        return enc._forward(x, training=enc.training)
+        y = enc._forward(x, training=enc.training)
+        ctx.gen = enc._gen                # the library keeps the saved activations of its LAST training forward only
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         enc = ctx.enc
+        if ctx.gen != enc._gen:
+            raise IsharaError("backward() of an encoder output whose saved activations were overwritten by a later forward pass of the same "
+                              "encoder: one live autograd graph per encoder (call backward() before the next forward, or use a second encoder "
+                              "object for a second branch)")
         dx = enc._backward(dy)
         return dx, enc.grads[:enc.n_train].clone(), None
 
@@ -120,6 +126,8 @@ class _TorchFamilyEncoder:
         self.training = True
         self.device = None
         self._seed, self._steps = seed * 7919 + 17, 0
+        self._gen = 0                     # forward passes so far (autograd graphs check it: the library saves ONE pass)
+        self._synced_version = -1         # `flat._version` at the last ishara_sync_weights
         if device is not None:
             self._to_device(device, seed)
 
@@ -202,8 +210,11 @@ class _TorchFamilyEncoder:
         self.sync_weights()
 
     def sync_weights(self):
-        """Re-derive the MFMA-typed weight copies after the flat parameters changed (an optimiser step on `enc.flat`)."""
+        """Re-derive the MFMA-typed weight copies after the flat parameters changed (an optimiser step on `enc.flat`).  `_forward`
+        calls it by itself whenever torch's version counter of the flat buffer moved since the last call (in-place optimiser steps,
+        `load_state_dict` bump it); writes that bypass the counter (`enc.flat.data...`, a raw pointer) need the explicit call."""
         _lib.check(self._lib.ishara_sync_weights(self._h, _stream()), "ishara_sync_weights")
+        self._synced_version = self.flat._version
 
     # ------------------------------------------------------------------ forward / backward
     def _forward(self, x: torch.Tensor, training: bool, seed: Optional[int] = None) -> torch.Tensor:
@@ -216,6 +227,9 @@ class _TorchFamilyEncoder:
         if B > self.max_batch:
             raise ValueError(f"batch {B} > max_batch {self.max_batch}")
         y = torch.empty((B, self.T_out, self.dim), dtype=torch.float32, device=self.device)
+        if self.flat._version != self._synced_version:      # the parameters moved (optimiser step): refresh the MFMA-typed copies first
+            self.sync_weights()
+        self._gen += 1
         if seed is None:
             seed = (self._seed + 0x9E3779B1 * self._steps) & 0xFFFFFFFF
             self._steps += 1
@@ -234,9 +248,15 @@ class _TorchFamilyEncoder:
         return default_state_dict(self.torch_shapes(), seed)
 
     def _apply(self, x):
+        """Training mode with grad enabled: differentiable through `_EncoderFn` — ONE live graph per encoder (the library keeps the
+        saved activations and the dropout seed of its last training forward; a stale graph's backward raises).  Eval mode returns a
+        constant (inference path, nothing saved): asking for a gradient w.r.t. the input there is an error, not a silent zero."""
         x = torch.as_tensor(x)
         if torch.is_grad_enabled() and self.training:
             return _EncoderFn.apply(x.to(self.device), self.flat, self)
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise IsharaError("eval-mode forward is not differentiable (no activations are saved): call enc.train() for gradients, or "
+                              "pass x.detach() / use torch.no_grad() for inference")
         return self._forward(x, training=self.training)
 
 

@@ -18,8 +18,9 @@ void ishara_set_error(const char* fmt, ...) {
 extern "C" const char* ishara_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ small kernels
-// fills inside forward / backward use a kernel rather than hipMemsetAsync: under hipGraph capture the memset NODES of this
-// ROCm build intermittently corrupted neighbouring workspace (tests/test_tflite_gpu.py, graph mode)
+// fills inside forward / backward use a kernel rather than hipMemsetAsync, so that a captured forward / training step holds kernel
+// nodes only.  (Round 1 blamed hipGraph memset nodes for intermittently wrong replays; round 2 could not reproduce that — 0 of 72 000
+// checks wrong with memset nodes, profiles/r2_graph_memset_experiment.txt — and withdrew the attribution: DESIGN.md §4.)
 __global__ void fill_u32_kernel(uint32_t* p, size_t n, uint32_t v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -839,6 +840,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
     if (m->family != ISHARA_FAMILY_KERAS_HYBRID) { ishara_set_error("ishara_loss_backward: this handle is an encoder-only family; use ishara_encoder_backward"); return -1; }
     if (B != m->lastB || !m->last_training) { ishara_set_error("ishara_loss_backward: call ishara_forward(training=1) with the same batch first"); return -1; }
     m->s = (hipStream_t)st;
+    m->tn_defer.pending = false;        // a previous backward pass that returned early (error path) must not leave slab sums behind for this one to add
     Run r{B, B * m->T, 1, m->last_seed};
     const int dt = m->dt, d = m->d, T = m->T;
     OpArgs no; EpiArgs e0;

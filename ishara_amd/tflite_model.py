@@ -23,6 +23,29 @@ N_COLS = 276
 PARTS = [("lip", 40), ("rhand", 21), ("lhand", 21), ("rpose", 5), ("lpose", 5)]
 FALLBACK_PHRASE = np.array([17, 0, 32, 12, 36, 0, 12, 32, 49, 46, 36], dtype=np.int64)     # c13:22-23
 
+# MediaPipe landmark ids behind the 92 selected landmarks (dataset metadata, c1:12-22): 40 lip points of the face mesh, the arm /
+# hand points of the pose model for the left (13..21 odd) and right (14..22 even) side
+LIP_IDS = (61, 185, 40, 39, 37, 0, 267, 269, 270, 409, 291, 146, 91, 181, 84, 17, 314, 405, 321, 375,
+           78, 191, 80, 81, 82, 13, 312, 311, 310, 415, 95, 88, 178, 87, 14, 317, 402, 318, 324, 308)
+LPOSE_IDS, RPOSE_IDS = tuple(range(13, 22, 2)), tuple(range(14, 23, 2))
+
+
+def selected_columns():
+    """SEL_COLS of the reference (c1:24-28): the parquet column names the 276 input features are read from — one block per axis
+    (x | y | z), inside a block right hand 0..20, left hand 0..20, left pose, right pose, lips."""
+    per_axis = ([("right_hand", i) for i in range(21)] + [("left_hand", i) for i in range(21)]
+                + [("pose", i) for i in LPOSE_IDS + RPOSE_IDS] + [("face", i) for i in LIP_IDS])
+    return [f"{axis}_{part}_{i}" for axis in "xyz" for part, i in per_axis]
+
+
+def write_inference_args(path: str = "inference_args.json") -> str:
+    """The side file the reference ships next to `model.tflite` (c14:9-10) and reads back in c15:1-2:
+    `{"selected_columns": SEL_COLS}`."""
+    import json
+    with open(path, "w") as f:
+        json.dump({"selected_columns": selected_columns()}, f)
+    return path
+
 
 class TFLiteModel:
     def __init__(self, model: Model, stats: Optional[Dict[str, tuple]] = None, max_frames: int = 1024, use_graph: bool = True):
@@ -89,6 +112,16 @@ class TFLiteModel:
         ok = idx < 59
         out[np.arange(idx.shape[0])[ok], idx[ok]] = 1.0
         return {"outputs": out}
+
+    def export(self, directory: str = ".", weights: str = "model.h5") -> Dict[str, str]:
+        """The export step of c14:1-10 as far as this build goes: the model's weights (`model.h5`, Keras-2 `save_weights` layout; use a
+        `.npz` name where libhdf5 is missing) and `inference_args.json`.  The fp16 numerics of the reference's `.tflite` are what
+        `get_model(dtype="f16")` runs; the flatbuffer container itself is not written (nothing in this image can validate one)."""
+        import os
+        os.makedirs(directory, exist_ok=True)
+        wpath = os.path.join(directory, weights)
+        self.model.save_weights(wpath)
+        return {"weights": wpath, "inference_args": write_inference_args(os.path.join(directory, "inference_args.json"))}
 
     # reference spelling: interpreter.get_signature_runner("serving_default")(inputs=frame)  (c16:10-13)
     def get_signature_runner(self, name: str = "serving_default"):

@@ -46,11 +46,16 @@ def test_inference_is_per_sample_and_matches_f32(models):
     f32 = mf(x, training=False)
     err = (full - f32).abs().max().item()
     assert err <= 0.15, f"bf16 vs f32 logits max-abs-err {err}"              # same tolerance as the oracle comparison
-    # greedy decode: identical indices wherever the f32 logits have no near-tie
-    top2 = torch.topk(f32, 2, dim=-1).values
-    clear = (top2[..., 0] - top2[..., 1]).min(dim=1).values > 0.5
+    # greedy decode at full size: the bf16 run's per-frame argmax equals the f32 run's on every frame the f32 logits resolve (top-2 margin
+    # above 2x the observed difference) — counted, so that an empty comparison cannot pass
+    from decode_check import frame_margins
+    f32n, fulln = f32.cpu().numpy(), full.cpu().numpy()
+    clear = frame_margins(f32n) > 2 * err
+    assert clear.sum() >= 0.25 * clear.size, f"only {int(clear.sum())}/{clear.size} frames resolved at logit error {err:.3f}"
+    assert (np.argmax(fulln, -1)[clear] == np.argmax(f32n, -1)[clear]).all()
     db, df = mb.decode_batch(full), mf.decode_batch(f32)
-    assert all(np.array_equal(db[i], df[i]) for i in range(B) if bool(clear[i]))
+    whole = [i for i in range(B) if clear[i].all()]
+    assert all(np.array_equal(db[i], df[i]) for i in whole)
     # decode is idempotent on its own logits
     assert all(np.array_equal(a, b) for a, b in zip(db, mb.decode_batch(full)))
 

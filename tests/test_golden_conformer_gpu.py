@@ -213,3 +213,49 @@ def test_product_encoder_running_stats_follow_torch_rule():
     want_v = 0.9 * sd[p + ".batch_norm.running_var"] + 0.1 * var
     np.testing.assert_allclose(after[p + ".batch_norm.running_mean"].numpy(), want_m.numpy(), rtol=0, atol=2e-5)
     np.testing.assert_allclose(after[p + ".batch_norm.running_var"].numpy(), want_v.numpy(), rtol=0, atol=2e-5)
+
+
+def test_forward_after_an_optimizer_step_uses_the_new_weights():
+    """`out = enc(x); loss.backward(); opt.step(); enc(x)` — the reference torch module (conformer.py:76-87) reads its parameters at
+    every forward.  The library multiplies MFMA-typed COPIES of the flat fp32 parameters: the forward pass must notice that
+    torch's version counter of `enc.flat` moved and re-derive them itself, in f32 and in bf16 mode."""
+    for dt in ("f32", "bf16"):
+        enc = _encoder(dt, 1).train()
+        x = torch.from_numpy(G["x"]).cuda()
+        opt = torch.optim.SGD(enc.parameters(), lr=0.05)
+        y0 = enc(x)
+        y0.square().mean().backward()
+        opt.step()
+        with torch.no_grad():
+            enc.eval()
+            auto = enc(x).clone()                  # no manual sync_weights()
+            enc.sync_weights()
+            manual = enc(x).clone()
+        assert torch.equal(auto, manual), dt
+        # and the step really changed the function (a stale copy would reproduce the old output)
+        stale = _encoder(dt, 1).eval()
+        with torch.no_grad():
+            before = stale(x)
+        assert (auto - before).abs().max() > 1e-3, dt
+
+
+def test_one_live_graph_per_encoder_and_eval_mode_gradients_are_errors():
+    """The library keeps the saved activations of its LAST training forward only: the backward of an older graph must raise
+    instead of returning gradients computed from the newer pass's activations; an eval-mode forward of an input that requires
+    grad must raise instead of returning a constant."""
+    from ishara_amd._lib import IsharaError
+    enc = _encoder("f32", 1).train()
+    x1 = torch.from_numpy(G["x"]).cuda().requires_grad_(True)
+    x2 = (torch.from_numpy(G["x"]).cuda() * 0.5).requires_grad_(True)
+    y1 = enc(x1)
+    y2 = enc(x2)
+    with pytest.raises(IsharaError, match="one live autograd graph"):
+        (y1.sum() + y2.sum()).backward()
+    y3 = enc(x1)                                   # the normal order still works afterwards
+    y3.sum().backward()
+    assert x1.grad is not None and torch.isfinite(x1.grad).all()
+    enc.eval()
+    with pytest.raises(IsharaError, match="eval-mode forward is not differentiable"):
+        enc(x1)
+    with torch.no_grad():
+        enc(x1)

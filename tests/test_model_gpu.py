@@ -85,15 +85,15 @@ def _log_observed(rec):
 BF16_TOL = dict(logits=0.15, loss=5e-3, grad=0.12, grad_small=0.2, stats=3e-2)   # observed on configs[1] / [3]: logits 0.07 / 0.13, loss 1.6e-4, gradients rel-L2 0.11 / 0.14
 
 
-def check_train_step(kw, dtype, dropout, tag, bf16_tol=BF16_TOL, check_decode=False):
+def check_train_step(kw, dtype, dropout, tag, bf16_tol=BF16_TOL, check_decode=False, min_frac_16=0.0):
     os.environ["ISHARA_WS_GUARD"] = "1"       # guard zones behind every workspace buffer (read at ishara_create), verified below
     try:
-        _check_train_step(kw, dtype, dropout, tag, bf16_tol, check_decode)
+        _check_train_step(kw, dtype, dropout, tag, bf16_tol, check_decode, min_frac_16)
     finally:
         os.environ.pop("ISHARA_WS_GUARD", None)
 
 
-def _check_train_step(kw, dtype, dropout, tag, bf16_tol, check_decode):
+def _check_train_step(kw, dtype, dropout, tag, bf16_tol, check_decode, min_frac_16=0.0):
     """One training step (forward, CTC, backward) of the HIP library vs the fp64 oracle on the same weights, batch and
     dropout seed: logits, loss, every parameter gradient, the BatchNorm moving statistics."""
     from oracle import ishara_oracle as O
@@ -127,17 +127,16 @@ def _check_train_step(kw, dtype, dropout, tag, bf16_tol, check_decode):
             if rg.size > 8 and e > gmax: gmax, gmax_name = e, n
             lim = bf16_tol["grad_small"] if rg.size <= 8 else bf16_tol["grad"]      # 5-tap ECA kernels: difference of bf16-rounded sums
             if e > lim: bad.append((n, e))
-    # greedy decode of the training logits against the oracle's, on the frames whose top-2 margin exceeds the logit error
-    dec_same = None
+    # greedy decode of the training logits against the oracle's: per-frame argmax on every frame whose oracle top-2 margin exceeds 2x the
+    # observed logit error, whole phrases on clips without an unresolved frame; the counts are asserted and logged (tests/decode_check.py)
+    dec_rec = None
     if check_decode:
-        top2 = np.sort(ref_logits, axis=2)[:, :, -2:]
-        margin = top2[:, :, 1] - top2[:, :, 0]
-        clear = margin.min(axis=1) > 2 * lerr
-        dec = model.decode_batch(logits_t)
-        dec_same = all(np.array_equal(dec[b], O.decode_phrase(ref_logits[b])) for b in range(kw["B"]) if clear[b])
+        from decode_check import check_decode_parity
+        dec_rec = check_decode_parity(ref_logits, logits, model.decode_batch(logits_t), O.decode_phrase, err=lerr,
+                                      min_frac=0.9 if dtype == "f32" else min_frac_16, what=f"{tag}[{dtype}]")
     _log_observed(dict(test=tag, dtype=dtype, dropout=dropout, logits_max_abs_err=lerr, loss=loss, ref_loss=ref_loss,
                        loss_rel_err=abs(loss - ref_loss) / abs(ref_loss), worst_grad_err=gmax, worst_grad=gmax_name,
-                       grad_metric="max-abs/max" if dtype == "f32" else "rel-L2", decode_equal=dec_same))
+                       grad_metric="max-abs/max" if dtype == "f32" else "rel-L2", decode=dec_rec))
     if dtype == "f32":
         assert lerr <= 1e-4, f"logits max-abs-err {lerr:.3e}"
         assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-4, (loss, ref_loss)
@@ -149,8 +148,6 @@ def _check_train_step(kw, dtype, dropout, tag, bf16_tol, check_decode):
     for n, rs in ref_stats.items():
         tol = 1e-4 if dtype == "f32" else bf16_tol["stats"]
         assert np.abs(W_after[n] - rs).max() <= tol * (1 + np.abs(rs).max()), n
-    if check_decode:
-        assert dec_same, "greedy decode indices differ from the oracle's on clips without a near-tie frame"
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -216,11 +213,10 @@ def test_inference_and_decode_parity(dtype):
     assert err <= (1e-4 if dtype == "f32" else 0.15), f"inference logits max-abs-err {err:.3e}"
     dec = model.decode_batch(logits)
     for b in range(kw["B"]):
-        want_self = O.decode_phrase(got[b])                 # integer path: bit exact on the same logits
-        assert np.array_equal(dec[b], want_self)
-        top2 = np.sort(ref[b], axis=1)[:, -2:]
-        if dtype == "f32" and (top2[:, 1] - top2[:, 0]).min() > 1e-3:   # no near-tie frame: indices identical to the oracle's
-            assert np.array_equal(dec[b], O.decode_phrase(ref[b]))
+        assert np.array_equal(dec[b], O.decode_phrase(got[b]))           # integer path: bit exact on the same logits
+    from decode_check import check_decode_parity
+    rec = check_decode_parity(ref, got, dec, O.decode_phrase, err=err, min_frac=0.9 if dtype == "f32" else 0.0, what=f"inference[{dtype}]")
+    _log_observed(dict(test="inference_decode[cfg1]", dtype=dtype, logits_max_abs_err=err, decode=rec))
 
 
 def test_optimizer_parity():
