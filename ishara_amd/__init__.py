@@ -5,4 +5,4 @@ from .model import (Callback, History, LearningRateScheduler, Model, Optimizer, 
                     get_model, lrfn, make_config)
 from ._lib import IsharaError  # noqa: F401
 from .conformer import ConformerEncoder  # noqa: F401  (torch family: conformer/conformer.py)
-from .squeezeformer import SqueezeformerEncoder  # noqa: F401  (torch family: squeezeformer/encoder.py)
+from .squeezeformer import Squeezeformer, SqueezeformerEncoder  # noqa: F401  (torch family: squeezeformer/encoder.py, model.py)

@@ -106,6 +106,8 @@ struct ShadowDesc { const float* W; void* Wt; void* Wn; int K, N, ldt, ldn, tile
 int launch_make_shadow_batched(int dtM, const ShadowDesc* tab, int ntab, int total_tiles, hipStream_t s);
 
 // ---- normalisation / conv / small ops (elementwise.hip) ---------------------------
+int launch_log_softmax_fwd(const float* x, float* y, int M, int C, hipStream_t s);
+int launch_log_softmax_bwd(const float* dy, const float* y, float* dx, int M, int C, hipStream_t s);
 int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float* beta, float eps,
                          void* y, float* mean, float* rstd, int M, int C, hipStream_t s);
 // dx = LN'(dy) (+ resid) ; dgamma/dbeta += column sums: through per-block partial rows in `scratch`

@@ -105,3 +105,107 @@ class SqueezeformerEncoder(_TorchFamilyEncoder):
         return y, self.output_lengths(torch.as_tensor(input_lengths).clone())
 
     forward = __call__
+
+
+class _FcLogSoftmaxFn(torch.autograd.Function):
+    """log_softmax(x @ W^T) over the class axis and its backward, every product and reduction in libishara_hip.so (`ishara_op_dense_fwd_ex`
+    / `ishara_op_dense_bwd` in exact-fp32 MFMA mode — the reference's output layer is fp32 — and `ishara_op_log_softmax_fwd / _bwd`);
+    torch only owns the buffers."""
+
+    @staticmethod
+    def forward(ctx, x, weight, lib):
+        import ctypes as C
+        from .model import _stream
+        B, T, d = x.shape
+        M, N = B * T, weight.shape[0]
+        x2 = x.detach().reshape(M, d).contiguous()
+        Wk = weight.detach().t().contiguous()                      # nn.Linear [C, d] -> the library's [K, N]
+        z = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(z)
+        sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, d, N)) + 256, dtype=torch.uint8, device=x.device)
+        scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+        _lib.check(lib.ishara_op_dense_fwd_ex(_lib.F32, _lib.ptr(x2), _lib.ptr(Wk), None, None, _lib.ptr(z), M, d, N, 0, scp, _stream()), "fc")
+        _lib.check(lib.ishara_op_log_softmax_fwd(_lib.ptr(z), _lib.ptr(y), M, N, _stream()), "log_softmax")
+        ctx.save_for_backward(x2, Wk, y)
+        ctx.lib, ctx.scratch, ctx.shape = lib, (sc, scp), (B, T, d, N)
+        return y.reshape(B, T, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .model import _stream
+        x2, Wk, y = ctx.saved_tensors
+        lib, (sc, scp), (B, T, d, N) = ctx.lib, ctx.scratch, ctx.shape
+        M = B * T
+        dy2 = dy.detach().reshape(M, N).to(torch.float32).contiguous()
+        dz = torch.empty_like(dy2)
+        _lib.check(lib.ishara_op_log_softmax_bwd(_lib.ptr(dy2), _lib.ptr(y), _lib.ptr(dz), M, N, _stream()), "log_softmax_bwd")
+        dx = torch.empty(M, d, dtype=torch.float32, device=dy.device)
+        dW = torch.zeros(d, N, dtype=torch.float32, device=dy.device)
+        db = torch.zeros(N, dtype=torch.float32, device=dy.device)
+        _lib.check(lib.ishara_op_dense_bwd(_lib.F32, _lib.ptr(x2), _lib.ptr(Wk), _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, d, N, scp, _stream()), "fc_bwd")
+        return dx.reshape(B, T, d), dW.t().contiguous(), None
+
+
+class Squeezeformer:
+    """`Squeezeformer(num_classes, input_dim, encoder_dim, ...)` of squeezeformer/model.py:366-450: the encoder above, the bias-free output
+    layer `fc = nn.Linear(encoder_dim, num_classes, bias=False)` (:431) and `log_softmax` (:449).  `model(inputs, input_lengths)` returns
+    `(log_probs [B, T_out, num_classes], output_lengths)` like the reference's forward (:437-450) and is differentiable end to end (the
+    encoder through `ishara_encoder_backward`, the head through the library's dense / log-softmax operators), so that
+    `torch.nn.functional.ctc_loss(log_probs.transpose(0, 1), ...)` or the library's own CTC kernel train it.  state_dict keys:
+    `encoder.<the encoder's keys>` and `fc.weight` [num_classes, encoder_dim]."""
+
+    def __init__(self, num_classes: int, input_dim: int = 80, encoder_dim: int = 512, num_encoder_layers: int = 16, reduce_layer_index: int = 7,
+                 recover_layer_index: int = 15, num_attention_heads: int = 8, feed_forward_expansion_factor: int = 4, conv_expansion_factor: int = 2,
+                 input_dropout_p: float = 0.1, feed_forward_dropout_p: float = 0.1, attention_dropout_p: float = 0.1, conv_dropout_p: float = 0.1,
+                 conv_kernel_size: int = 31, half_step_residual: bool = False, *, seq_len: int = 384, max_batch: int = 16, dtype: str = "bf16",
+                 device: Optional[str] = "cuda:0", seed: int = 0):
+        self.encoder = SqueezeformerEncoder(input_dim, encoder_dim, num_encoder_layers, reduce_layer_index, recover_layer_index, num_attention_heads,
+                                            feed_forward_expansion_factor, conv_expansion_factor, input_dropout_p, feed_forward_dropout_p,
+                                            attention_dropout_p, conv_dropout_p, conv_kernel_size, half_step_residual,
+                                            seq_len=seq_len, max_batch=max_batch, dtype=dtype, device=device, seed=seed)
+        self.num_classes = num_classes
+        g = torch.Generator().manual_seed(seed + 1)
+        w = (torch.rand(num_classes, encoder_dim, generator=g) * 2 - 1) * encoder_dim ** -0.5        # nn.Linear's default U(+-1/sqrt(fan_in))
+        self.fc_weight = torch.nn.Parameter(w.to(self.encoder.device), requires_grad=True)
+        self.training = True
+
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        self.encoder.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def parameters(self):
+        return self.encoder.parameters() + [self.fc_weight]
+
+    def zero_grad(self):
+        self.encoder.zero_grad()
+        self.fc_weight.grad = None
+
+    def count_parameters(self) -> int:
+        """model.py:433-435 means the ENCODER's parameter count (the reference's own method raises: :249 sums `p.numel` without calling it)."""
+        return self.encoder.n_train
+
+    def state_dict(self):
+        sd = OrderedDict(("encoder." + k, v) for k, v in self.encoder.state_dict().items())
+        sd["fc.weight"] = self.fc_weight.detach().cpu().clone()
+        return sd
+
+    def load_state_dict(self, sd, strict: bool = True):
+        self.encoder.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=strict)
+        if "fc.weight" in sd:
+            with torch.no_grad():
+                self.fc_weight.copy_(torch.as_tensor(sd["fc.weight"]).to(self.fc_weight.device, torch.float32))
+        elif strict:
+            raise KeyError("load_state_dict: missing fc.weight")
+
+    def __call__(self, inputs, input_lengths):
+        enc_out, out_len = self.encoder(inputs, input_lengths)
+        if torch.is_grad_enabled() and self.training:
+            return _FcLogSoftmaxFn.apply(enc_out, self.fc_weight, self.encoder._lib), out_len
+        with torch.no_grad():
+            return _FcLogSoftmaxFn.apply(enc_out, self.fc_weight, self.encoder._lib), out_len
+
+    forward = __call__

@@ -248,3 +248,11 @@ def output_length(T: int, cfg: Dict) -> int:
         if cfg["recover_layer_index"] < cfg["num_layers"]:
             t = 2 * t
     return t
+
+
+def squeezeformer_top(x, P, cfg: Dict, training=False, stats=None) -> torch.Tensor:
+    """Squeezeformer.forward (squeezeformer/model.py:437-450): encoder -> `fc` (bias-free Linear, :431) -> log_softmax over the classes.
+    P holds the top-level state_dict: `encoder.*` and `fc.weight`; cfg uses the encoder's key names (`num_layers` = num_encoder_layers)."""
+    Pe = {k[len("encoder."):]: v for k, v in P.items() if k.startswith("encoder.")}
+    h, _ = encoder(x, Pe, cfg, training, stats)
+    return torch.log_softmax(h @ P["fc.weight"].t(), dim=-1)
