@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
                 const float p = (g0 + j < nk) ? __expf(s[j] - mn) : 0.f;
                 l += p;
                 float pd = p;
-                if (drop.thr) pd = rng_keep(rk, (uint32_t)(k0 + g0 + j), drop.thr) ? p * drop.scale : 0.f;
+                if (drop.thr) pd = rng_keep_q(rk, (uint32_t)(k0 + g0 + j), drop.thr) ? p * drop.scale : 0.f;
 #pragma unroll
                 for (int i = 0; i < DHL; ++i) acc[i] += pd * Vs[(g0 + j) * DH + sub * DHL + i];
             }
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
             const float s = quad_sum(ps) * scale;
             float dp = quad_sum(pv);
             const float p = __expf(s - ls);
-            if (drop.thr) dp = rng_keep(rk, (uint32_t)(k0 + j), drop.thr) ? dp * drop.scale : 0.f;
+            if (drop.thr) dp = rng_keep_q(rk, (uint32_t)(k0 + j), drop.thr) ? dp * drop.scale : 0.f;
             const float ds = p * (dp - dl) * scale;
 #pragma unroll
             for (int i = 0; i < DHL; ++i) dq[i] += ds * Ks[j * DH + sub * DHL + i];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
             const float p = __expf(s - Ls[j]);
             float pd = p;
             if (drop.thr) {
-                const bool keep = rng_keep(rng_row_key(drop.key, (uint32_t)(bh * Tn + q0 + j)), (uint32_t)key, drop.thr);
+                const bool keep = rng_keep_q(rng_row_key(drop.key, (uint32_t)(bh * Tn + q0 + j)), (uint32_t)key, drop.thr);
                 pd = keep ? p * drop.scale : 0.f;
                 dp = keep ? dp * drop.scale : 0.f;
             }

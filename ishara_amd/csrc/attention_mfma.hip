@@ -185,11 +185,10 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_fwd_mfma_kernel(co
                     l_run[t] += pv;
                     p[kt][r] = pv;
                 }
-                if constexpr (DM != 0) {      // 4 consecutive keys: 2 hashes; the keep bits are remembered for the backward kernels
-                    // one compare per score serves both the select and the bit (the 1/(1-rate) factor is applied once per output below)
-                    const uint32_t col4 = (uint32_t)(key0 + 16 * kt + 4 * g);
-                    const uint32_t h0 = rng_pair(rkey, col4), h1 = rng_pair(rkey, col4 + 2);
-                    const bool k0 = (h0 & 0xffffu) >= drop.thr, k1 = (h0 >> 16) >= drop.thr, k2 = (h1 & 0xffffu) >= drop.thr, k3 = (h1 >> 16) >= drop.thr;
+                if constexpr (DM != 0) {      // 4 consecutive keys: ONE hash, a byte per key (common.h rng_quad); the keep bits are remembered for the backward kernels
+                    // one compare per score serves both the select and the bit (the 1/P(keep) factor is applied once per output below)
+                    const uint32_t h0 = rng_quad(rkey, (uint32_t)(key0 + 16 * kt + 4 * g));
+                    const bool k0 = (h0 & 0xffu) >= drop.thr, k1 = ((h0 >> 8) & 0xffu) >= drop.thr, k2 = ((h0 >> 16) & 0xffu) >= drop.thr, k3 = (h0 >> 24) >= drop.thr;
                     p[kt][0] = k0 ? p[kt][0] : 0.f; p[kt][1] = k1 ? p[kt][1] : 0.f; p[kt][2] = k2 ? p[kt][2] : 0.f; p[kt][3] = k3 ? p[kt][3] : 0.f;
                     if constexpr (DM == 2) {
                         constexpr_shift_or(keepbits, k0, k1, k2, k3, 16 * t + 4 * kt);
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dq_mfma_kernel
                     for (int r = 0; r < 4; ++r) dp[r] = dpa[kt][t][r];
                     if constexpr (DM != 0) {
                         // keep bits of the forward pass when it stored them (same lane layout), else the hash again
-                        const uint32_t kb4 = DM == 2 ? (keepbits >> (16 * t + 4 * kt)) & 15u : rng_bits4(rkey, (uint32_t)(key0 + 16 * kt + 4 * g), drop.thr);
+                        const uint32_t kb4 = DM == 2 ? (keepbits >> (16 * t + 4 * kt)) & 15u : rng_bits4_q(rkey, (uint32_t)(key0 + 16 * kt + 4 * g), drop.thr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) dp[r] = ((kb4 >> r) & 1u) ? dp[r] * drop.scale : 0.f;
                     }
@@ -563,7 +562,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 3 : 2) void attn_bwd_dkv_mfma_kerne
                         float dp = dpa[hq][r], pdv = pv;
                         if constexpr (DM != 0) {
                             const bool keep = DM == 2 ? ((mw[t][r] >> (16 * hq + 4 * (((kbase + 16 * t) % AF_KC) >> 4) + (c & 3))) & 1u) != 0u
-                                                      : rng_keep(Rc[ql], key, drop.thr);
+                                                      : rng_keep_q(Rc[ql], key, drop.thr);
                             dp = keep ? dp * drop.scale : 0.f;
                             pdv = keep ? pv : 0.f;                     // * drop.scale once per dV output (epilogue)
                         }
@@ -825,7 +824,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_fused_kernel(const b
                                 dp = __uint_as_float(__float_as_uint(dp * drop.scale) & km);
                                 pdv = __uint_as_float(__float_as_uint(pv) & km);      // * drop.scale once per dV output
                             } else if constexpr (DM != 0) {
-                                const bool keep = rng_keep(rkv[hq][r], key, drop.thr);
+                                const bool keep = rng_keep_q(rkv[hq][r], key, drop.thr);
                                 dp = keep ? dp * drop.scale : 0.f;
                                 pdv = keep ? pv : 0.f;
                             }

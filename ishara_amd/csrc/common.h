@@ -143,7 +143,23 @@ __host__ __device__ __forceinline__ bool rng_keep(uint32_t row_key, uint32_t col
     const uint32_t h = rng_pair(row_key, col);
     return ((col & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr;
 }
+// Attention-PROBABILITY dropout (the [T,T] score matrices: 302 M decisions per layer in config #2, where the hash was 40 % of the forward
+// kernel's VALU issue slots) draws FOUR decisions from one hash: keys 4k .. 4k+3 of a query row share lowbias32(row_key ^ k), key 4k+e
+// takes byte e.  keep iff byte >= thr8 = round(rate * 256): P(keep) = 1 - thr8/256 (rate 0.2 -> 0.80078, 0.1 -> 0.89844), and the kept
+// probabilities are scaled by 256/(256 - thr8) = 1/P(keep), so the expectation is exact for the rate actually drawn.  Mirrored by
+// oracle/rng.py (keep_mask_attn).
+__host__ __device__ __forceinline__ uint32_t rng_quad(uint32_t row_key, uint32_t col) {
+    return lowbias32(row_key ^ (col >> 2));
+}
+__host__ __device__ __forceinline__ bool rng_keep_q(uint32_t row_key, uint32_t col, uint32_t thr8) {
+    return ((rng_quad(row_key, col) >> (8u * (col & 3u))) & 0xffu) >= thr8;
+}
 #if defined(__HIPCC__)
+// keep flags (bit e) of the 4 consecutive keys starting at a multiple of 4: ONE hash
+__device__ __forceinline__ uint32_t rng_bits4_q(uint32_t row_key, uint32_t col4, uint32_t thr8) {
+    const uint32_t h = rng_quad(row_key, col4);
+    return ((h & 0xffu) >= thr8 ? 1u : 0u) | (((h >> 8) & 0xffu) >= thr8 ? 2u : 0u) | (((h >> 16) & 0xffu) >= thr8 ? 4u : 0u) | ((h >> 24) >= thr8 ? 8u : 0u);
+}
 // keep flags (bit e) of the 4 consecutive columns starting at a multiple of 4: two hashes
 __device__ __forceinline__ uint32_t rng_bits4(uint32_t row_key, uint32_t col4, uint32_t thr) {
     const uint32_t h0 = rng_pair(row_key, col4), h1 = rng_pair(row_key, col4 + 2);
@@ -177,6 +193,17 @@ static inline DropSpec make_drop(uint32_t seed, uint32_t site, float rate, bool 
     d.key = rng_site_key(seed, site);
     d.thr = (training && rate > 0.f) ? rng_threshold(rate) : 0u;
     d.scale = (training && rate > 0.f) ? 1.0f / (1.0f - rate) : 1.0f;
+    return d;
+}
+
+// attention-probability sites: 8-bit threshold, scale = 1 / P(keep) of the quantised rate (see rng_quad)
+static inline DropSpec make_drop_attn(uint32_t seed, uint32_t site, float rate, bool training) {
+    DropSpec d;
+    d.key = rng_site_key(seed, site);
+    double t = (double)rate * 256.0 + 0.5;
+    uint32_t thr8 = (training && rate > 0.f) ? (uint32_t)(t < 0 ? 0 : (t > 255.0 ? 255.0 : t)) : 0u;
+    d.thr = thr8;
+    d.scale = thr8 ? 256.0f / (256.0f - (float)thr8) : 1.0f;
     return d;
 }
 

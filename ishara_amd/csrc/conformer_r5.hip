@@ -168,7 +168,7 @@ static int r5_mhsa_fwd(ishara_model* m, R5MHSA& a, const Run& r, const void* x) 
     CK(gemm_fwd(m, a.Wqkv, x, dt, nullptr, dt, r.M, OP_NONE, no, eq));
     const float scale = 1.0f / sqrtf((float)m->dh);      // nn.MultiheadAttention: q * head_dim ** -0.5
     CKP(m, "attn_fwd", 4.0 * r.M * m->d * (double)dt_size(dt), 4.0 * r.B * m->H * (double)m->T * m->T * m->dh,
-        launch_attn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->Wf(a.lse), r.B, m->H, m->T, m->dh, scale, dspec(r, a.site_attn, m->cfg.dropout_rate),
+        launch_attn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->Wf(a.lse), r.B, m->H, m->T, m->dh, scale, dspec_attn(r, a.site_attn, m->cfg.dropout_rate),
                         m->cfg.attn_impl, reinterpret_cast<uint32_t*>(m->W(a.maskw)), m->s));
     EpiArgs ep; ep.resid = x;
     CK(gemm_fwd(m, a.Wp, m->W(a.o), dt, m->W(a.r), dt, r.M, OP_NONE, no, ep));
@@ -237,7 +237,7 @@ static int r5_mhsa_bwd(ishara_model* m, R5MHSA& a, const Run& r, const void* x, 
     const float scale = 1.0f / sqrtf((float)m->dh);
     CKP(m, "attn_bwd", 8.0 * r.M * m->d * (double)dt_size(dt), 10.0 * r.B * m->H * (double)m->T * m->T * m->dh,
         launch_attn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta), m->W(m->t2), r.B, m->H, m->T, m->dh, scale,
-                        dspec(r, a.site_attn, m->cfg.dropout_rate), 1, m->cfg.attn_impl, reinterpret_cast<uint32_t*>(m->W(a.maskw)), m->s));
+                        dspec_attn(r, a.site_attn, m->cfg.dropout_rate), 1, m->cfg.attn_impl, reinterpret_cast<uint32_t*>(m->W(a.maskw)), m->s));
     EpiArgs e1; e1.resid = dr;
     CK(gemm_dgrad(m, a.Wqkv, m->W(m->t2), dt, gn, r.M, OP_NONE, no, e1));
     CK(gemm_wgrad(m, a.Wqkv, x, dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));

@@ -496,6 +496,11 @@ int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop
 }
 
 
+// keep-bit cache of the attention-probability dropout (forward writes, backward reads); ISHARA_NO_ATTN_BITS=1: both passes hash instead (A/B switch)
+static uint32_t* attn_maskw(ishara_model* m, const Buf& off) {
+    static const bool off_env = getenv("ISHARA_NO_ATTN_BITS") != nullptr;
+    return off_env ? nullptr : reinterpret_cast<uint32_t*>(m->W(off));
+}
 int wgrad_flush(ishara_model* m) { return launch_gemm_tn_flush(&m->tn_defer, m->s); }
 
 // LayerNorm as a prologue of the GEMM that consumes it (gemm_as.hip): the wave holds whole rows of K, so the statistics cost two
@@ -594,7 +599,7 @@ static int mhsa_fwd(ishara_model* m, MHSA& a, const Run& r, const void* x) {
     CK(gemm_fwd(m, a.Wqkv, ain, dt, nullptr, dt, r.M, OP_NONE, no, eq));
     const float scale = 1.0f / sqrtf((float)m->d);     // self.scale = dim ** -0.5 (c5:95)
     CKP(m, "attn_fwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 4.0 * r.B * m->H * (double)m->T * m->T * m->dh, launch_attn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->Wf(a.lse), r.B, m->H, m->T, m->dh, scale,
-                       dspec(r, a.site_attn, a.rate), m->cfg.attn_impl, reinterpret_cast<uint32_t*>(m->W(a.maskw)), m->s));
+                       dspec_attn(r, a.site_attn, a.rate), m->cfg.attn_impl, attn_maskw(m, a.maskw), m->s));
     EpiArgs ep; ep.resid = x;
     if (a.has_out_drop) ep.drop = dspec(r, a.site_out, m->cfg.dropout_rate);
     CK(gemm_fwd(m, a.Wp, m->W(a.o), dt, m->W(a.out), dt, r.M, OP_NONE, no, ep));
@@ -781,7 +786,7 @@ static int mhsa_bwd(ishara_model* m, MHSA& a, const Run& r, const void* x, const
     CK(gemm_wgrad(m, a.Wp, m->W(a.o), dt, OP_NONE, no, gs, dt, OP_NONE, no, r.M));
     const float scale = 1.0f / sqrtf((float)m->d);
     CKP(m, "attn_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 10.0 * r.B * m->H * (double)m->T * m->T * m->dh, launch_attn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vt), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta), m->W(m->t2),
-                       r.B, m->H, m->T, m->dh, scale, dspec(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, reinterpret_cast<uint32_t*>(m->W(a.maskw)), m->s));
+                       r.B, m->H, m->T, m->dh, scale, dspec_attn(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, attn_maskw(m, a.maskw), m->s));
     CK(gemm_dgrad(m, a.Wqkv, m->W(m->t2), dt, m->W(m->t1), r.M, OP_NONE, no, e0));            // dxn
     CK(gemm_wgrad(m, a.Wqkv, m->W(a.xn), dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
     CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), m->Wf(m->slab), r.M, m->d, m->s));
@@ -1099,12 +1104,12 @@ extern "C" int ishara_op_attn_fwd(int32_t dt, const void* qkv, void* o, int32_t 
     attn_scratch((char*)scratch, dt, B, H, T, dh, q, k, vt, lse, delta, maskw);
     if (dt == DT_BF16) hipLaunchKernelGGL(qkv_split_kernel<bf16>, dim3(1024), dim3(256), 0, s, (const bf16*)qkv, (bf16*)q, (bf16*)k, (bf16*)vt, B, H, T, dh);
     else hipLaunchKernelGGL(qkv_split_kernel<float>, dim3(1024), dim3(256), 0, s, (const float*)qkv, (float*)q, (float*)k, (float*)vt, B, H, T, dh);
-    return launch_attn_fwd(dt, q, k, vt, o, lse, B, H, T, dh, scale, make_drop(seed, site, rate, true), impl, maskw, s);
+    return launch_attn_fwd(dt, q, k, vt, o, lse, B, H, T, dh, scale, make_drop_attn(seed, site, rate, true), impl, maskw, s);
 }
 extern "C" int ishara_op_attn_bwd(int32_t dt, const void* o, const void* dout, void* dqkv, int32_t B, int32_t H, int32_t T, int32_t dh, float scale,
                                   uint32_t seed, uint32_t site, float rate, int32_t impl, void* scratch, ishara_stream st) {
     hipStream_t s = (hipStream_t)st;
     void *q, *k, *vt; float *lse, *delta; uint32_t* maskw;
     attn_scratch((char*)scratch, dt, B, H, T, dh, q, k, vt, lse, delta, maskw);
-    return launch_attn_bwd(dt, q, k, vt, o, dout, lse, delta, dqkv, B, H, T, dh, scale, make_drop(seed, site, rate, true), 1, impl, maskw, s);
+    return launch_attn_bwd(dt, q, k, vt, o, dout, lse, delta, dqkv, B, H, T, dh, scale, make_drop_attn(seed, site, rate, true), 1, impl, maskw, s);
 }

@@ -183,6 +183,7 @@ struct ishara_model {
 // ------------------------------------------------------------------ shared helpers (model.hip)
 struct Run { int B, M, training; uint32_t seed; };
 static inline DropSpec dspec(const Run& r, uint32_t site, float rate) { return make_drop(r.seed, site, rate, r.training != 0); }
+static inline DropSpec dspec_attn(const Run& r, uint32_t site, float rate) { return make_drop_attn(r.seed, site, rate, r.training != 0); }   // attention probabilities: common.h rng_quad
 void plan_shadow(ishara_model* m, DenseW& w, int min_ldt = 0, int min_ldn = 0);
 // profiled GEMM launches over a planned Dense weight: forward C = epi(A W), dgrad dX = epi(dY W^T), wgrad dW += A^T dY (+ bias grad)
 int gemm_fwd(ishara_model* m, const DenseW& w, const void* A, int dtA, void* Cc, int dtC, int M, int aop, const OpArgs& oa, EpiArgs ea);

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(RA_QB) void relattn_fwd_kernel(const T* __restrict_
             s *= scale;
             const float mn = fmaxf(mx, s), corr = __expf(mx - mn), p = __expf(s - mn);
             l = l * corr + p;
-            const float pd = (drop.thr == 0u || rng_keep(rk, (uint32_t)(j0 + jj), drop.thr)) ? p * drop.scale : 0.f;
+            const float pd = (drop.thr == 0u || rng_keep_q(rk, (uint32_t)(j0 + jj), drop.thr)) ? p * drop.scale : 0.f;
 #pragma unroll
             for (int e = 0; e < DH; ++e) acc[e] = acc[e] * corr + pd * Vs[jj][e];
             mx = mn;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(RA_QB) void relattn_bwd_dq_kernel(const T* __restri
 #pragma unroll
             for (int e = 0; e < DH; ++e) { s += qu[e] * Ks[jj][e] + qv[e] * Ps[pr0 + jj][e]; dp += go[e] * Vs[jj][e]; }
             const float p = __expf(s * scale - L);
-            if (!(drop.thr == 0u || rng_keep(rk, (uint32_t)(j0 + jj), drop.thr))) dp = 0.f; else dp *= drop.scale;
+            if (!(drop.thr == 0u || rng_keep_q(rk, (uint32_t)(j0 + jj), drop.thr))) dp = 0.f; else dp *= drop.scale;
             const float dS = p * (dp - D) * scale;
 #pragma unroll
             for (int e = 0; e < DH; ++e) { dqc[e] += dS * Ks[jj][e]; dqp[e] += dS * Ps[pr0 + jj][e]; }
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(RA_QB) void relattn_bwd_dkv_kernel(const T* __restr
 #pragma unroll
             for (int e = 0; e < DH; ++e) { s += Qs[ii][e] * kk[e] + (Qs[ii][e] + vbv[e]) * Ps[pr][e]; dp += Gs[ii][e] * vv[e]; }
             const float p = __expf(s * scale - Ls[ii]);
-            const bool keep = drop.thr == 0u || rng_keep(rng_row_key(drop.key, (uint32_t)(bh * Tn + i0 + ii)), (uint32_t)j, drop.thr);
+            const bool keep = drop.thr == 0u || rng_keep_q(rng_row_key(drop.key, (uint32_t)(bh * Tn + i0 + ii)), (uint32_t)j, drop.thr);
             const float pd = keep ? p * drop.scale : 0.f;
             dp = keep ? dp * drop.scale : 0.f;
             const float dS = p * (dp - Ds[ii]) * scale;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(RA_QB) void relattn_bwd_dpos_kernel(const T* __rest
 #pragma unroll
             for (int e = 0; e < DH; ++e) { s += (Qs[ii][e] + uu[e]) * Ks[jl][e] + (Qs[ii][e] + vbv[e]) * pp[e]; dp += Gs[ii][e] * Vs[jl][e]; }
             const float p = __expf(s * scale - Ls[ii]);
-            const bool keep = drop.thr == 0u || rng_keep(rng_row_key(drop.key, (uint32_t)(bh * Tn + i0 + ii)), (uint32_t)j, drop.thr);
+            const bool keep = drop.thr == 0u || rng_keep_q(rng_row_key(drop.key, (uint32_t)(bh * Tn + i0 + ii)), (uint32_t)j, drop.thr);
             dp = keep ? dp * drop.scale : 0.f;
             const float dS = p * (dp - Ds[ii]) * scale;
 #pragma unroll
@@ -722,7 +722,7 @@ static int r4_mhsa_fwd(ishara_model* m, R4State* S, R4Layer& L, const Run& r, co
     const float scale = 1.0f / sqrtf((float)m->dh);
     CKP(m, "relattn_fwd", 4.0 * r.M * d * (double)dt_size(dt), 8.0 * r.B * m->H * (double)T * T * m->dh,
         launch_relattn_fwd(dt, m->W(a.q), m->W(a.k), m->W(a.vv), m->Wf(a.posp), m->P(a.u), m->P(a.v), m->W(a.o), m->Wf(a.lse), r.B, m->H, T, m->dh, scale,
-                           dspec(r, a.site_attn, m->cfg.dropout_rate), m->s));
+                           dspec_attn(r, a.site_attn, m->cfg.dropout_rate), m->s));
     EpiArgs ep; ep.resid = x; ep.drop = dspec(r, a.site_out, m->cfg.dropout_rate);
     CK(gemm_fwd(m, a.Wo, m->W(a.o), dt, m->W(a.r), dt, r.M, OP_NONE, no, ep));
     return r5_ln_fwd(m, r, m->W(a.r), a.ln, m->W(a.out), a.mean, a.rstd);
@@ -803,7 +803,7 @@ static int r4_mhsa_bwd(ishara_model* m, R4State* S, R4Layer& L, const Run& r, co
     CKP(m, "relattn_bwd", 12.0 * r.M * d * (double)dt_size(dt), 24.0 * r.B * m->H * (double)T * T * m->dh,
         launch_relattn_bwd(dt, m->W(a.q), m->W(a.k), m->W(a.vv), m->Wf(a.posp), m->P(a.u), m->P(a.v), m->W(a.o), m->W(m->t1), m->Wf(a.lse), m->Wf(m->delta),
                            m->W(S->dqb), m->W(S->dkb), m->W(S->dvb), m->G(a.u), m->G(a.v), m->Wf(S->dposp), r.B, m->H, T, m->dh, scale,
-                           dspec(r, a.site_attn, m->cfg.dropout_rate), m->s));
+                           dspec_attn(r, a.site_attn, m->cfg.dropout_rate), m->s));
     // pos_proj weight gradient: table^T . dposp (no bias, the table itself has no gradient)
     CK(gemm_wgrad(m, a.Wpos, m->dt == DT_F32 ? (const void*)m->Wf(S->pe32[L.pe]) : (const void*)m->W(S->pedt[L.pe]), dt, OP_NONE, no, m->Wf(S->dposp), DT_F32, OP_NONE, no, 2 * T - 1));
     // the three input projections: dx = dr + dq Wq^T + dk Wk^T + dv Wv^T

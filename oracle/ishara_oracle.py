@@ -196,14 +196,15 @@ class _Sites:
     def __init__(self, seed, training):
         self.seed, self.training, self.n = seed, training, 0
 
-    def mask(self, rows, cols, rate, ref: torch.Tensor):
+    def mask(self, rows, cols, rate, ref: torch.Tensor, attn: bool = False):
         """Returns multiplicative mask tensor [rows, cols] or None; always
-        consumes one site id so ids stay aligned with the HIP library."""
+        consumes one site id so ids stay aligned with the HIP library.  attn: an attention-probability
+        site (one hash per four keys, 8-bit threshold: oracle/rng.py keep_mask_attn)."""
         site = self.n
         self.n += 1
         if not self.training or rate <= 0.0:
             return None
-        m = rng.scaled_mask(self.seed, site, rows, cols, rate, dtype=np.float64)
+        m = (rng.scaled_mask_attn if attn else rng.scaled_mask)(self.seed, site, rows, cols, rate, dtype=np.float64)
         return torch.from_numpy(m).to(ref.dtype)
 
 
@@ -290,7 +291,7 @@ def mhsa(x, P, name, cfg, rate, sites):
     qkv = dense(x, P, f"{name}/qkv", bias=False).view(B, T, H, 3 * dh).permute(0, 2, 1, 3)
     q, k, v = qkv[..., :dh], qkv[..., dh:2 * dh], qkv[..., 2 * dh:]
     attn = torch.softmax((q @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1)
-    m = sites.mask(B * H * T, T, rate, x)
+    m = sites.mask(B * H * T, T, rate, x, attn=True)
     if m is not None:
         attn = attn * m.view(B, H, T, T)
     o = (attn @ v).permute(0, 2, 1, 3).reshape(B, T, d)

@@ -219,7 +219,7 @@ def test_attention(lib, dt, B, H, T, dh, rate, impl):
     _lib.check(lib.ishara_op_attn_fwd(code, _lib.ptr(qd), _lib.ptr(o), B, H, T, dh, C.c_float(scale), seed, site, C.c_float(rate), impl, scp, stream()))
     mask = None
     if rate > 0:
-        mask = torch.from_numpy(rng.scaled_mask(seed, site, B * H * T, T, rate, dtype=np.float64)).view(B, H, T, T)
+        mask = torch.from_numpy(rng.scaled_mask_attn(seed, site, B * H * T, T, rate, dtype=np.float64)).view(B, H, T, T)
     qr = qkv.double().requires_grad_(True)
     ref = _attn_ref(qr, B, H, T, dh, scale, mask)
     close(o, ref, "attn_fwd", **TOL[dt])

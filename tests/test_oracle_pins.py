@@ -145,3 +145,45 @@ def test_batchnorm_training_statistics_and_dropout_determinism():
     assert l1 == l2 and np.array_equal(lg1, lg2) and not np.array_equal(lg1, lg3)
     assert set(s1) == {n for n, _, _, t in O.param_specs(cfg) if not t}
     assert all(v is not None for v in g1.values())
+
+
+def test_attention_quad_rng_statistics():
+    """The attention-probability generator draws four 8-bit decisions from one lowbias32 hash (common.h rng_quad; oracle/rng.py
+    keep_mask_attn).  The checks a weaker (one-round) hash failed in round 2, applied to the byte lanes: overall keep rate, per-row
+    keep-rate spread against the binomial, correlation between neighbouring columns at lags 1-4 (inside and across a quad), between
+    neighbouring rows, chi-square of every byte lane's value histogram, and independence of the four lanes of one hash."""
+    rows, cols, rate = 2048, 384, 0.2
+    t8 = int(rng.threshold8(rate))
+    p = 1.0 - t8 / 256.0
+    m = rng.keep_mask_attn(11, 5, rows, cols, rate).astype(np.float64)
+    assert abs(m.mean() - p) < 4 * np.sqrt(p * (1 - p) / m.size)
+    row_rate = m.mean(axis=1)
+    assert 0.8 < row_rate.std() / np.sqrt(p * (1 - p) / cols) < 1.2          # binomial spread (the one-round hash: 5x)
+    col_rate = m.mean(axis=0)
+    assert 0.8 < col_rate.std() / np.sqrt(p * (1 - p) / rows) < 1.2
+    z = m - p
+    for lag in (1, 2, 3, 4, 5, 8):
+        r = float((z[:, :-lag] * z[:, lag:]).mean() / (p * (1 - p)))
+        assert abs(r) < 5 / np.sqrt(z[:, lag:].size), (lag, r)                # one-round hash: -0.17 at lag 2
+    r = float((z[:-1] * z[1:]).mean() / (p * (1 - p)))
+    assert abs(r) < 5 / np.sqrt(z[1:].size), r
+    # byte lanes of the raw hash: uniform histograms, and pairwise-independent lanes (chi-square on the 16x16 table of the top nibbles)
+    ks = rng.site_key(11, 5)
+    with np.errstate(over="ignore"):
+        key_row = rng.lowbias32(ks ^ (np.arange(rows, dtype=np.uint32) * np.uint32(0x85EBCA6B)))
+    h = rng.lowbias32(key_row[:, None] ^ np.arange(cols // 4, dtype=np.uint32)[None, :]).reshape(-1)
+    lanes = [((h >> np.uint32(8 * e)) & np.uint32(0xFF)).astype(np.int64) for e in range(4)]
+    n = h.size
+    for e in range(4):
+        cnt = np.bincount(lanes[e], minlength=256)
+        chi = float(((cnt - n / 256) ** 2 / (n / 256)).sum())
+        assert chi < 255 + 5 * np.sqrt(2 * 255), (e, chi)                     # one-round hash: 1612 at 255 d.o.f.
+    for a in range(4):
+        for b in range(a + 1, 4):
+            tab = np.bincount((lanes[a] >> 4) * 16 + (lanes[b] >> 4), minlength=256).astype(np.float64)
+            chi = float(((tab - n / 256) ** 2 / (n / 256)).sum())
+            assert chi < 255 + 5 * np.sqrt(2 * 255), (a, b, chi)
+    # scale = 1 / P(keep): the mask has unit expectation for the rate actually drawn
+    sm = rng.scaled_mask_attn(11, 5, rows, cols, rate, dtype=np.float64)
+    assert abs(sm.mean() - 1.0) < 4 * np.sqrt((1 - p) / p / sm.size)
+    assert (rng.scaled_mask_attn(1, 1, 4, 8, 0.0) == 1).all()
