@@ -175,8 +175,29 @@ def run_training(args):
     for _ in range(args.steps):
         loss = model.train_on_batch(x, y)
     torch.cuda.synchronize(); parallel.barrier()
-    dt = parallel.reduce_max(time.perf_counter() - t0, device=dev)
+    dt_local = time.perf_counter() - t0
+    dt = parallel.reduce_max(dt_local, device=dev)
     loss_v = float(loss.item())
+    # N > 1 diagnostics (outside the timed region, every rank takes part): each rank's own step time, the flat gradient all-reduce alone,
+    # and the step without the exchange -> how much of the all-reduce the step exposes
+    diag = None
+    if world > 1:
+        per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+        per_rank[rank] = dt_local / args.steps * 1e3
+        dist.all_reduce(per_rank)
+        k = max(3, min(10, args.steps))
+        flat = model.grads[:model.n_train]
+        parallel.barrier(); torch.cuda.synchronize(); ta = time.perf_counter()
+        for _ in range(k):
+            parallel.allreduce_sum_(flat)
+        torch.cuda.synchronize(); ar_ms = parallel.reduce_max(time.perf_counter() - ta, device=dev) / k * 1e3
+        parallel.barrier(); torch.cuda.synchronize(); tb = time.perf_counter()
+        for _ in range(k):
+            model.train_on_batch(x, y, allreduce=False)
+        torch.cuda.synchronize(); noar_ms = parallel.reduce_max(time.perf_counter() - tb, device=dev) / k * 1e3
+        diag = {"per_rank_ms_per_step": [round(float(v), 4) for v in per_rank.cpu()], "allreduce_alone_ms": ar_ms,
+                "allreduce_bytes": int(flat.numel()) * 4, "ms_per_step_without_allreduce": noar_ms,
+                "exposed_allreduce_ms": dt / args.steps * 1e3 - noar_ms, "diagnostic_steps": k}
 
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     # one more step with every launch bracketed by HIP events; EVERY rank runs it (the step contains the gradient
@@ -189,6 +210,10 @@ def run_training(args):
     ms = dt / args.steps * 1e3
     value = world * B * T * args.steps / dt
     fam, roof = roofline_of(prof, cfg, value / world)
+    # the profiled step brackets every launch with events and therefore runs the weight-gradient slab sums as launches of their own
+    # (`reduce_slabs(wgrad)`); in the timed steps they ride as extra workgroups of the next weight-gradient GEMM: kernels_ms is the
+    # non-deferred launch sequence and does not sum to ms_per_step
+    roof["profiled_path"] = "non-deferred slab sums (timed steps: deferred riders)"
     if B == cfg["batch"] and args.dtype == "bf16":
         roof["traffic"], roof["traffic_source"] = committed_traffic(fam, f"cfg{args.config}")
     else:
@@ -200,7 +225,8 @@ def run_training(args):
         "config": {"workload": cfg["workload"], "batch_per_gpu": B, "global_batch": B * world,
                    "frames": T, "features": F, "params": model.n_total, "parallelism": f"dp{world}", "loss": loss_v,
                    "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
-                   "allreduce": ("bucketed+overlapped" if parallel.overlap_enabled() else "flat") if world > 1 else None},
+                   "allreduce": ("bucketed+overlapped" if parallel.overlap_enabled() else "flat") if world > 1 else None,
+                   "multi_gpu_diagnostics": diag},
         "roofline": roof,
         "kernels_ms": {k: round(v["ms"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
     }

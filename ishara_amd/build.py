@@ -15,7 +15,8 @@ def source_hash() -> str:
     import glob
     import hashlib
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "ishara_hip.h")]
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(os.path.dirname(HERE), "include", "ishara_hip.h"),
+                                                                                                 os.path.join(CSRC, "Makefile")]      # build flags are part of the build
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())

@@ -298,11 +298,16 @@ class Model:
         self.optimizer.iterations += 1
         self._steps += 1
 
-    def train_on_batch(self, x, y, seed: Optional[int] = None) -> torch.Tensor:
+    def train_on_batch(self, x, y, seed: Optional[int] = None, allreduce: bool = True) -> torch.Tensor:
         """One Keras train_step (c12): forward, CTC, backward, [RCCL grad all-reduce], update.
-        Returns the device loss tensor (no host sync)."""
+        Returns the device loss tensor (no host sync).  `allreduce=False` skips the gradient exchange (bench.py's diagnostic
+        of the exposed all-reduce time; replicas diverge — never for training)."""
         from . import parallel
         world = parallel.world_size()
+        if not allreduce:
+            loss, _ = self.loss_and_gradients(x, y, seed=seed, loss_scale=1.0 / world)
+            self.apply_gradients()
+            return loss
         overlap = world > 1 and parallel.overlap_enabled()
         if overlap:
             self.enable_grad_buckets()
