@@ -168,10 +168,11 @@ int ishara_op_dense_fwd_ex(int32_t dt, const void* x, const float* W, const floa
 /* dx = dy @ W^T ; dW += x^T dy ; db += colsum(dy) */
 int ishara_op_dense_bwd(int32_t dt, const void* x, const float* W, const void* dy, void* dx,
                         float* dW, float* db, int32_t M, int32_t K, int32_t N, void* scratch, ishara_stream s);
-/* y[m,:] = x[m,:] - logsumexp(x[m,:]) over C fp32 logits; dx = dy - exp(y) * rowsum(dy).  Replaces F.log_softmax(self.fc(...), dim=-1) of the
+/* y[m,:C] = x[m,:C] - logsumexp(x[m,:C]) over C fp32 logits in rows of stride ld >= C floats (columns C..ld-1 of the outputs are zeroed: a class
+ * count padded to the GEMMs' 16-byte row alignment); dx = dy - exp(y) * rowsum(dy).  Replaces F.log_softmax(self.fc(...), dim=-1) of the
  * reference's torch Squeezeformer (squeezeformer/model.py:448-449). */
-int ishara_op_log_softmax_fwd(const float* x, float* y, int32_t M, int32_t C, ishara_stream s);
-int ishara_op_log_softmax_bwd(const float* dy, const float* y, float* dx, int32_t M, int32_t C, ishara_stream s);
+int ishara_op_log_softmax_fwd(const float* x, float* y, int32_t M, int32_t C, int32_t ld, ishara_stream s);
+int ishara_op_log_softmax_bwd(const float* dy, const float* y, float* dx, int32_t M, int32_t C, int32_t ld, ishara_stream s);
 int ishara_op_layernorm_fwd(int32_t dt, const void* x, const float* gamma, const float* beta, float eps,
                             void* y, float* mean, float* rstd, int32_t M, int32_t C, ishara_stream s);
 int ishara_op_layernorm_bwd(int32_t dt, const void* dy, const void* x, const float* mean, const float* rstd,

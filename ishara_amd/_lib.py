@@ -71,8 +71,8 @@ SIGNATURES = {
     "ishara_op_dense_fwd": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "ishara_op_dense_fwd_ex": (C.c_int, [_I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "ishara_op_dense_bwd": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
-    "ishara_op_log_softmax_fwd": (C.c_int, [_P, _P, _I32, _I32, _P]),
-    "ishara_op_log_softmax_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _P]),
+    "ishara_op_log_softmax_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "ishara_op_log_softmax_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P]),
     "ishara_op_layernorm_fwd": (C.c_int, [_I32, _P, _P, _P, _F, _P, _P, _P, _I32, _I32, _P]),
     "ishara_op_layernorm_bwd": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ishara_op_dwconv_fwd": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

@@ -1712,10 +1712,10 @@ int launch_map_rows(int dt, int op, const void* x, void* y, const float* rs, Dro
 // `F.log_softmax(self.fc(encoder_outputs), dim=-1)` — squeezeformer/model.py:448-449.  One wavefront per row of C fp32 logits
 // (C is a class count: tens to a few thousand), exact two-pass form in registers/loop: max, then sum of exp, cross-lane by DPP
 // butterflies; a workgroup of 4 waves takes 4 rows per iteration of a grid-stride loop.
-__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int C) {
+__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int C, int ld) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int m = blockIdx.x * 4 + w; m < M; m += gridDim.x * 4) {
-        const float* xr = x + (size_t)m * C;
+        const float* xr = x + (size_t)m * ld;
         float mx = -INFINITY;
         for (int c = lane; c < C; c += 64) mx = fmaxf(mx, xr[c]);
 #pragma unroll
@@ -1725,31 +1725,33 @@ __global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const float* __res
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o, 64);
         const float lse = mx + __logf(se);
-        float* yr = y + (size_t)m * C;
+        float* yr = y + (size_t)m * ld;
         for (int c = lane; c < C; c += 64) yr[c] = xr[c] - lse;
+        for (int c = C + lane; c < ld; c += 64) yr[c] = 0.f;          // padding columns of the row stride
     }
 }
 // dx = dy - exp(y) * sum_c dy      (y = the forward's output)
-__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, int M, int C) {
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, int M, int C, int ld) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int m = blockIdx.x * 4 + w; m < M; m += gridDim.x * 4) {
-        const float* gr = dy + (size_t)m * C;
-        const float* yr = y + (size_t)m * C;
+        const float* gr = dy + (size_t)m * ld;
+        const float* yr = y + (size_t)m * ld;
         float s = 0.f;
         for (int c = lane; c < C; c += 64) s += gr[c];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-        float* dr = dx + (size_t)m * C;
+        float* dr = dx + (size_t)m * ld;
         for (int c = lane; c < C; c += 64) dr[c] = gr[c] - __expf(yr[c]) * s;
+        for (int c = C + lane; c < ld; c += 64) dr[c] = 0.f;
     }
 }
-int launch_log_softmax_fwd(const float* x, float* y, int M, int C, hipStream_t s) {
-    if (M < 1 || C < 1) { ishara_set_error("log_softmax: M=%d C=%d", M, C); return -1; }
-    hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3(max(1, min((M + 3) / 4, 2048))), dim3(256), 0, s, x, y, M, C);
+int launch_log_softmax_fwd(const float* x, float* y, int M, int C, int ld, hipStream_t s) {
+    if (M < 1 || C < 1 || ld < C) { ishara_set_error("log_softmax: M=%d C=%d ld=%d", M, C, ld); return -1; }
+    hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3(max(1, min((M + 3) / 4, 2048))), dim3(256), 0, s, x, y, M, C, ld);
     return LAUNCH_OK();
 }
-int launch_log_softmax_bwd(const float* dy, const float* y, float* dx, int M, int C, hipStream_t s) {
-    if (M < 1 || C < 1) { ishara_set_error("log_softmax: M=%d C=%d", M, C); return -1; }
-    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(max(1, min((M + 3) / 4, 2048))), dim3(256), 0, s, dy, y, dx, M, C);
+int launch_log_softmax_bwd(const float* dy, const float* y, float* dx, int M, int C, int ld, hipStream_t s) {
+    if (M < 1 || C < 1 || ld < C) { ishara_set_error("log_softmax: M=%d C=%d ld=%d", M, C, ld); return -1; }
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(max(1, min((M + 3) / 4, 2048))), dim3(256), 0, s, dy, y, dx, M, C, ld);
     return LAUNCH_OK();
 }

@@ -68,13 +68,17 @@ template <int GW, typename T> DEVI void as_st(T* p, const float (&v)[GW]) {
 }
 // the same with the non-temporal hint: tensors that are only read again in the BACKWARD pass (saved pre-activations, the prologues'
 // transformed rows) should not push the tensors the next launch reads out of L2 / Infinity Cache
-template <int GW, typename T> DEVI void as_st_nt(T* p, const float (&v)[GW]) {
+template <int GW, typename T> DEVI void as_st_nt(T* p, const float (&v)[GW], bool nt = true) {
     if constexpr (GW == 8 && is_16b_t<T>::value) {
         as_v8 t;
 #pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = (as_t)v[i];
-        __builtin_nontemporal_store(t, reinterpret_cast<as_v8*>(p));
+        if (nt) __builtin_nontemporal_store(t, reinterpret_cast<as_v8*>(p)); else *reinterpret_cast<as_v8*>(p) = t;
     } else as_st<GW>(p, v);
+}
+// packed 16-byte store of an already converted group
+DEVI void as_st_pk(as_t* p, const as_v8& t, bool nt) {
+    if (nt) __builtin_nontemporal_store(t, reinterpret_cast<as_v8*>(p)); else *reinterpret_cast<as_v8*>(p) = t;
 }
 // 16 bytes of TC -> GW floats (8 bf16 / 4 f32)
 template <typename TC, int GW> DEVI void as_unpack(const as_u32x4& r, float (&v)[GW]) {
@@ -118,6 +122,12 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
     constexpr int SPS = RT * NG;                   // stores per lane per step
     constexpr bool COUNTED = (MASK & (AS_RESID | AS_DACT | AS_ADDTAB | AS_QKV)) == 0;   // epilogue = a fixed number of stores, no loads
     constexpr int OPS = SPS * ((MASK & AS_PREOUT) ? 2 : 1);
+    // HOLD: the 16-byte groups of an even column step wait, packed, in registers and are stored together with the next (odd) step's: the two
+    // 64-byte halves of every row's 128-byte line then reach L2 back to back.  One step apart (~2 us) the first half has often left L2 for
+    // cold HBM before the second arrives, and such half-line writes run at 3.8 TB/s against 4.6+ for whole lines (tools/micro/store_cold.hip).
+    constexpr bool HOLDABLE = PAIR && std::is_same<TC, as_t>::value && MASK != AS_ALL && (MASK & AS_QKV) == 0;
+    const bool hold = HOLDABLE && (ea.as_flags & 1) && !ea.n_valid;
+    const bool nt_side = (ea.as_flags & 2) != 0;
 
     const int dbg = DBG ? ea.dbg : 0;          // ablation bits of tools/gemm_ablate.py, compiled out of the production kernels
     const int tid = threadIdx.x, lane = tid & 63;
@@ -280,13 +290,22 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
         asm volatile("" : "+v"(rsc[i]));
     }
 
+    as_v8 held[RT], held_pre[RT];         // HOLD: the even step's packed groups (main output, saved pre-activation)
+#pragma unroll
+    for (int i = 0; i < RT; ++i) { held[i] = as_v8{}; held_pre[i] = as_v8{}; }
     int slot = 0;
     for (int s = 0; s < nsteps; ++s) {
         // ---- T1: stage s has landed.  Younger operations that may stay in flight (in-order VM counter): the DMAs of
         // stages s+1 .. s+R-2 and, when the epilogue is a fixed number of stores and the row block is full, the stores
         // of the R-1 steps since its issue.
         if constexpr (COUNTED) {
-            if (full && s >= R - 1 && s + R - 2 < nsteps) as_wait_vm<(R - 2) * DPW + (R - 1) * OPS>(); else as_wait_vm<0>();
+            if (full && !ea.n_valid && s >= R - 1 && s + R - 2 < nsteps) {
+                if (!hold) as_wait_vm<(R - 2) * DPW + (R - 1) * OPS>();
+                // held stores leave in pairs at the odd steps: of the two steps since stage s was requested exactly one was odd (R = 3);
+                // with R = 2 only the step before this one counts — a pair when it was odd, nothing when it was even
+                else if constexpr (R == 3) as_wait_vm<DPW + 2 * OPS>();
+                else { if (s & 1) as_wait_vm<0>(); else as_wait_vm<2 * OPS>(); }
+            } else as_wait_vm<0>();
         } else {
             if (s + R - 2 < nsteps) as_wait_vm<(R - 2) * DPW>(); else as_wait_vm<0>();
         }
@@ -383,7 +402,19 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
                         for (int e = 0; e < 4; ++e) v[4 * h + e] += t4[e];
                     }
                 }
-                if (f_preout) as_st_nt<GW>(reinterpret_cast<TC*>(ea.pre_out) + off, v);
+                if (f_preout) {
+                    if constexpr (HOLDABLE) {
+                        if (hold) {
+                            as_v8 t;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) t[e] = (as_t)v[e];
+                            as_t* pp = reinterpret_cast<as_t*>(ea.pre_out) + off;
+                            if (s & 1) { as_st_pk(pp - NS, held_pre[i], nt_side); as_st_pk(pp, t, nt_side); }
+                            else if (s == nsteps - 1) as_st_pk(pp, t, nt_side);
+                            else held_pre[i] = t;
+                        } else as_st_nt<GW>(reinterpret_cast<TC*>(ea.pre_out) + off, v, nt_side);
+                    } else as_st_nt<GW>(reinterpret_cast<TC*>(ea.pre_out) + off, v, nt_side);
+                }
                 if (f_act) {
                     if (ea.act == ACT_SWISH) {
 #pragma unroll
@@ -418,7 +449,17 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
                     for (int e = 0; e < GW; ++e) v[e] += x[e];
                 }
                 if (!f_qkv) {
-                    as_st<GW>(C + off, v);
+                    if constexpr (HOLDABLE) {
+                        if (hold) {
+                            as_v8 t;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) t[e] = (as_t)v[e];
+                            as_t* cp = reinterpret_cast<as_t*>(C) + off;
+                            if (s & 1) { as_st_pk(cp - NS, held[i], false); as_st_pk(cp, t, false); }
+                            else if (s == nsteps - 1) as_st_pk(cp, t, false);
+                            else held[i] = t;
+                        } else as_st<GW>(C + off, v);
+                    } else as_st<GW>(C + off, v);
                 } else {      // q,k [B,H,T,dh] rows; v transposed to vt [B,H,dh,T]   (GW consecutive columns stay inside one head: dh % 8 == 0)
                     int h, part, ii;
                     if (ea.head_major) { h = n / (3 * ea.dh); const int w = n - h * 3 * ea.dh; part = w / ea.dh; ii = w - part * ea.dh; }
@@ -446,7 +487,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
                 if (m < M) {
                     as_v8* p = reinterpret_cast<as_v8*>(reinterpret_cast<as_t*>(ea.pro_out) + (size_t)m * K + g * 8);
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) __builtin_nontemporal_store(a[i][kt], &p[kt * 4]);
+                    for (int kt = 0; kt < KT; ++kt) as_st_pk(reinterpret_cast<as_t*>(&p[kt * 4]), a[i][kt], nt_side);
                 }
             }
         }
@@ -504,8 +545,15 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
 }
 
 #define AS_LAUNCH(MASK) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
+// library default of EpiArgs.as_flags (bit 0 paired half-line stores, bit 1 non-temporal side outputs); ISHARA_AS_FLAGS overrides (A/B runs)
+static int as_default_flags() {
+    static const int v = getenv("ISHARA_AS_FLAGS") ? atoi(getenv("ISHARA_AS_FLAGS")) : 3;
+    return v;
+}
 template <typename TC, int KT>
-static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea, hipStream_t s) {
+static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea_in, hipStream_t s) {
+    EpiArgs ea = ea_in;
+    if (ea.as_flags < 0) ea.as_flags = as_default_flags();
     const int BR = KT <= 8 ? (M <= AS_SMALL_M ? 64 : 128) : (KT <= 16 ? (M <= AS_MID_M_K512 ? 64 : 192) : 128);     // rows per workgroup
     // few rows (config #4 at small batches: M / 192 = 171 workgroups for 512 slots): split the columns 2- or 4-way; every
     // workgroup then loads its A rows again, which is cheap exactly when M is small

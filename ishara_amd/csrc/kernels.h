@@ -52,6 +52,10 @@ struct EpiArgs {
     // A-stationary kernel only: C rows are ldc elements apart (0: N) and only the columns below n_valid are stored (0: all) — a 60-column
     // classifier runs as N = 64 over the zero-padded weight shadow (no residual / act' operands with these)
     int ldc = 0, n_valid = 0;
+    // A-stationary kernel, 16-bit C: bit 0 — a row's two 64-byte halves of a 128-byte line are stored back to back every second column step
+    // instead of one step apart (cold HBM takes half lines that arrive a step apart at 3.8 TB/s, whole lines at 4.6+: tools/micro/store_cold.hip);
+    // bit 1 — non-temporal hint on the side outputs (saved pre-activations, prologue rows).  -1: the library default (gemm_as.hip, ISHARA_AS_FLAGS)
+    int as_flags = -1;
 };
 
 // C[M,N] = epi( op(A)[M,K] . Bt[N,K]^T ).  Bt is a padded weight shadow: rows padded to
@@ -106,8 +110,8 @@ struct ShadowDesc { const float* W; void* Wt; void* Wn; int K, N, ldt, ldn, tile
 int launch_make_shadow_batched(int dtM, const ShadowDesc* tab, int ntab, int total_tiles, hipStream_t s);
 
 // ---- normalisation / conv / small ops (elementwise.hip) ---------------------------
-int launch_log_softmax_fwd(const float* x, float* y, int M, int C, hipStream_t s);
-int launch_log_softmax_bwd(const float* dy, const float* y, float* dx, int M, int C, hipStream_t s);
+int launch_log_softmax_fwd(const float* x, float* y, int M, int C, int ld, hipStream_t s);
+int launch_log_softmax_bwd(const float* dy, const float* y, float* dx, int M, int C, int ld, hipStream_t s);
 int launch_layernorm_fwd(int dt, const void* x, const float* gamma, const float* beta, float eps,
                          void* y, float* mean, float* rstd, int M, int C, hipStream_t s);
 // dx = LN'(dy) (+ resid) ; dgamma/dbeta += column sums: through per-block partial rows in `scratch`

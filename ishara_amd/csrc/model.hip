@@ -1066,8 +1066,8 @@ extern "C" int ishara_op_dense_bwd(int32_t dt, const void* x, const float* Wm, c
     return launch_gemm_tn(dt, dt, dt, OP_NONE, OP_NONE, x, dy, dW, db, (float*)(sc + slab), M, K, N, no, no, s);
 }
 // row log-softmax over fp32 logits and its backward: the output layer of the torch Squeezeformer (squeezeformer/model.py:448-449)
-extern "C" int ishara_op_log_softmax_fwd(const float* x, float* y, int32_t M, int32_t C, ishara_stream s) { return launch_log_softmax_fwd(x, y, M, C, (hipStream_t)s); }
-extern "C" int ishara_op_log_softmax_bwd(const float* dy, const float* y, float* dx, int32_t M, int32_t C, ishara_stream s) { return launch_log_softmax_bwd(dy, y, dx, M, C, (hipStream_t)s); }
+extern "C" int ishara_op_log_softmax_fwd(const float* x, float* y, int32_t M, int32_t C, int32_t ld, ishara_stream s) { return launch_log_softmax_fwd(x, y, M, C, ld, (hipStream_t)s); }
+extern "C" int ishara_op_log_softmax_bwd(const float* dy, const float* y, float* dx, int32_t M, int32_t C, int32_t ld, ishara_stream s) { return launch_log_softmax_bwd(dy, y, dx, M, C, ld, (hipStream_t)s); }
 extern "C" int ishara_op_layernorm_fwd(int32_t dt, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd, int32_t M, int32_t C, ishara_stream s) {
     return launch_layernorm_fwd(dt, x, gamma, beta, eps, y, mean, rstd, M, C, (hipStream_t)s);
 }

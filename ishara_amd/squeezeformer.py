@@ -118,32 +118,35 @@ class _FcLogSoftmaxFn(torch.autograd.Function):
         from .model import _stream
         B, T, d = x.shape
         M, N = B * T, weight.shape[0]
+        Np = (N + 7) // 8 * 8                                      # class count padded to the GEMMs' 16-byte row alignment (zero weight columns)
         x2 = x.detach().reshape(M, d).contiguous()
-        Wk = weight.detach().t().contiguous()                      # nn.Linear [C, d] -> the library's [K, N]
-        z = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        Wk = torch.zeros(d, Np, dtype=torch.float32, device=x.device)
+        Wk[:, :N] = weight.detach().t()                            # nn.Linear [C, d] -> the library's [K, N]
+        z = torch.empty(M, Np, dtype=torch.float32, device=x.device)
         y = torch.empty_like(z)
-        sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, d, N)) + 256, dtype=torch.uint8, device=x.device)
+        sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, d, Np)) + 256, dtype=torch.uint8, device=x.device)
         scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
-        _lib.check(lib.ishara_op_dense_fwd_ex(_lib.F32, _lib.ptr(x2), _lib.ptr(Wk), None, None, _lib.ptr(z), M, d, N, 0, scp, _stream()), "fc")
-        _lib.check(lib.ishara_op_log_softmax_fwd(_lib.ptr(z), _lib.ptr(y), M, N, _stream()), "log_softmax")
+        _lib.check(lib.ishara_op_dense_fwd_ex(_lib.F32, _lib.ptr(x2), _lib.ptr(Wk), None, None, _lib.ptr(z), M, d, Np, 0, scp, _stream()), "fc")
+        _lib.check(lib.ishara_op_log_softmax_fwd(_lib.ptr(z), _lib.ptr(y), M, N, Np, _stream()), "log_softmax")
         ctx.save_for_backward(x2, Wk, y)
-        ctx.lib, ctx.scratch, ctx.shape = lib, (sc, scp), (B, T, d, N)
-        return y.reshape(B, T, N)
+        ctx.lib, ctx.scratch, ctx.shape = lib, (sc, scp), (B, T, d, N, Np)
+        return y[:, :N].reshape(B, T, N)
 
     @staticmethod
     def backward(ctx, dy):
         from .model import _stream
         x2, Wk, y = ctx.saved_tensors
-        lib, (sc, scp), (B, T, d, N) = ctx.lib, ctx.scratch, ctx.shape
+        lib, (sc, scp), (B, T, d, N, Np) = ctx.lib, ctx.scratch, ctx.shape
         M = B * T
-        dy2 = dy.detach().reshape(M, N).to(torch.float32).contiguous()
+        dy2 = torch.zeros(M, Np, dtype=torch.float32, device=dy.device)
+        dy2[:, :N] = dy.detach().reshape(M, N)
         dz = torch.empty_like(dy2)
-        _lib.check(lib.ishara_op_log_softmax_bwd(_lib.ptr(dy2), _lib.ptr(y), _lib.ptr(dz), M, N, _stream()), "log_softmax_bwd")
+        _lib.check(lib.ishara_op_log_softmax_bwd(_lib.ptr(dy2), _lib.ptr(y), _lib.ptr(dz), M, N, Np, _stream()), "log_softmax_bwd")
         dx = torch.empty(M, d, dtype=torch.float32, device=dy.device)
-        dW = torch.zeros(d, N, dtype=torch.float32, device=dy.device)
-        db = torch.zeros(N, dtype=torch.float32, device=dy.device)
-        _lib.check(lib.ishara_op_dense_bwd(_lib.F32, _lib.ptr(x2), _lib.ptr(Wk), _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, d, N, scp, _stream()), "fc_bwd")
-        return dx.reshape(B, T, d), dW.t().contiguous(), None
+        dW = torch.zeros(d, Np, dtype=torch.float32, device=dy.device)
+        db = torch.zeros(Np, dtype=torch.float32, device=dy.device)
+        _lib.check(lib.ishara_op_dense_bwd(_lib.F32, _lib.ptr(x2), _lib.ptr(Wk), _lib.ptr(dz), _lib.ptr(dx), _lib.ptr(dW), _lib.ptr(db), M, d, Np, scp, _stream()), "fc_bwd")
+        return dx.reshape(B, T, d), dW[:, :N].t().contiguous(), None
 
 
 class Squeezeformer:

@@ -65,6 +65,11 @@ int main() {
         run<32, 32, 3, 0, 0>(bufs, NBUF, M, N); run<32, 64, 2, 0, 0>(bufs, NBUF, M, N);
         run<4, 32, 3, 0, 4>(bufs, NBUF, M, N); run<4, 64, 2, 0, 8>(bufs, NBUF, M, N);
         run<2, 32, 3, 0, 4>(bufs, NBUF, M, N); run<16, 32, 3, 0, 4>(bufs, NBUF, M, N);
+        // spaced steps (a GEMM column step between the stores): does completing a row's 128-B line by two back-to-back instructions recover the
+        // full-line rate?  and the non-temporal hint on each shape
+        run<4, 64, 3, 0, 8>(bufs, NBUF, M, N); run<4, 64, 3, 1, 8>(bufs, NBUF, M, N);
+        run<4, 64, 2, 1, 8>(bufs, NBUF, M, N); run<4, 32, 3, 1, 4>(bufs, NBUF, M, N);
+        run<4, 32, 3, 0, 2>(bufs, NBUF, M, N); run<4, 64, 3, 0, 4>(bufs, NBUF, M, N); run<4, 64, 2, 0, 4>(bufs, NBUF, M, N);
     }
     return 0;
 }
