@@ -167,6 +167,12 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
     for (int st = 0; st < R - 1; ++st)
         if (st < nsteps && !(dbg & 8)) issue(st * STAGE);       // dbg: ablation bits of tools/gemm_ablate.py (1 no epilogue, 2 no MFMA, 4 no LDS reads, 8 no DMA)
 
+    // experiment (ISHARA_AS_FLAGS bits 8..15): start skew — a third of the workgroups waits one / two units of ~1 us before loading their
+    // rows, so that the chip is not all reading and then all writing
+    if (const int skew = (ea.as_flags >> 8) & 255) {
+        const int grp = (int)(blockIdx.x >> 3) / 32 % 3;
+        for (int w = 0; w < grp * skew; ++w) asm volatile("s_sleep 32" ::: "memory");
+    }
     // A fragments: lane (c, g) holds row 16i + c, k = 32kt + 8g .. +7
     as_v8 a[RT][KT];
     int mrow[RT];
