@@ -88,11 +88,13 @@ def committed_traffic(family: str, tag: str):
     """HBM bytes per launch of `family` from the committed rocprofv3 --pmc passes (tools/traffic.py), but ONLY when that table
     was measured on the sources this .so was built from (source_hash stamp); PMC counters cannot be read live in-process."""
     from ishara_amd.build import source_hash
-    path = os.path.join(ROOT, "profiles", f"r2_traffic_{tag}.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{tag}.json")), key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
+    path = cands[-1] if cands else os.path.join(ROOT, "profiles", f"traffic_{tag}.json")      # the latest round's table
     try:
         tab = json.load(open(path))
     except (OSError, ValueError):
-        return None, f"no committed PMC table ({os.path.basename(path)})"
+        return None, f"no committed PMC table (profiles/r*_traffic_{tag}.json)"
     if tab.get("source_hash") != source_hash():
         return None, f"{os.path.basename(path)} was measured on another build (stamp {tab.get('source_hash')} != {source_hash()}): not quoted"
     kern = tab.get("kernels", {})
