@@ -1724,14 +1724,73 @@ static bool reduce_cols_ok(const float* slab, const float* out0, const float* ou
     return n % 4 == 0 && n0 % 4 == 0 && stride % 4 == 0 && ((uintptr_t)slab) % 16 == 0;
 }
 
+// ---- the deferred form: every recorded job in one launch.  A workgroup = 16 slab lanes x 16 column quads (64 columns of one job); the jobs'
+// first block indices ride in the kernel arguments (scalar loads), the body is reduce_slabs_cols_kernel<16, 16>'s.
+RedSink* g_red_sink = nullptr;
+struct RedBatch { RedJob job[RED_MAXJOBS]; int njobs; };
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(RedBatch b) {
+    constexpr int SL = 16, CQ = 16;
+    __shared__ float4 red[SL][CQ];
+    int j = 0;
+    for (int t = 1; t < b.njobs; ++t) if ((int)blockIdx.x >= b.job[t].first_block) j = t;      // uniform: scalar compares
+    const RedJob J = b.job[j];
+    const int tid = threadIdx.x, cq = tid % CQ, sl = tid / CQ;
+    const int col = ((int)blockIdx.x - J.first_block) * (CQ * 4) + cq * 4;
+    const int cin = J.nb ? (col < J.n0 ? col % J.nb : col - J.n0) : 0;
+    const bool valid = col < J.n && (J.nb == 0 || cin < J.nbv);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        for (int s0 = sl; s0 < J.splits; s0 += SL * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sidx = s0 + SL * u;
+                v[u] = sidx < J.splits ? *reinterpret_cast<const float4*>(J.slab + (size_t)sidx * J.stride + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+    }
+    red[sl][cq] = acc;
+    __syncthreads();
+    if (sl == 0 && valid) {
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int w = 1; w < SL; ++w) { t.x += red[w][cq].x; t.y += red[w][cq].y; t.z += red[w][cq].z; t.w += red[w][cq].w; }
+        float* dst = col < J.n0 ? (J.nb ? J.out0 + (size_t)(col / J.nb) * J.nbv + cin : J.out0 + col) : J.out1 + (col - J.n0);
+        dst[0] += t.x; dst[1] += t.y; dst[2] += t.z; dst[3] += t.w;
+    }
+}
+bool reduce_sink_full() { return g_red_sink && g_red_sink->njobs >= RED_MAXJOBS - 2; }
+static bool reduce_sink_take(const float* slab, float* out0, float* out1, int n0, int n, int splits, size_t stride, int nb, int nbv) {
+    RedSink* k = g_red_sink;
+    if (!k || k->njobs >= RED_MAXJOBS || !reduce_cols_ok(slab, out0, out1, n0, n, stride)) return false;
+    RedJob& J = k->job[k->njobs++];
+    J.slab = slab; J.out0 = out0; J.out1 = out1; J.stride = stride; J.n0 = n0; J.n = n; J.splits = splits; J.nb = nb; J.nbv = nbv;
+    J.first_block = k->nblocks;
+    k->nblocks += (n + 63) / 64;
+    return true;
+}
+int launch_reduce_flush(RedSink* sink, hipStream_t s) {
+    if (!sink || sink->njobs == 0) return 0;
+    RedBatch b;
+    for (int i = 0; i < sink->njobs; ++i) b.job[i] = sink->job[i];
+    b.njobs = sink->njobs;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(sink->nblocks), dim3(256), 0, s, b);
+    sink->njobs = 0; sink->nblocks = 0;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // out0[0..n0) += column sums of slab[:, 0..n0), out1[0..n1) += column sums of slab[:, n0..n0+n1)   (slab rows `stride` floats apart)
 void launch_reduce_slabs2(const float* slab, float* out0, int n0, float* out1, int n1, int splits, size_t stride, hipStream_t s, int nb, int nbv) {
+    if (reduce_sink_take(slab, out0, out1, n0, n0 + n1, splits, stride, nb, nbv)) return;
     if (reduce_cols_ok(slab, out0, out1, n0, n0 + n1, stride)) { launch_reduce_cols(slab, out0, out1, n0, n0 + n1, splits, stride, s, nb, nbv); return; }
     launch_reduce_slabs(slab, out0, n0, splits, stride, s);
     if (out1 && n1 > 0) launch_reduce_slabs(slab + n0, out1, n1, splits, stride, s);
 }
 
 void launch_reduce_slabs(const float* slab, float* out, int n, int splits, size_t stride, hipStream_t s) {
+    if (reduce_sink_take(slab, out, nullptr, n, n, splits, stride, 0, 0)) return;
     if (reduce_cols_ok(slab, out, nullptr, n, n, stride)) { launch_reduce_cols(slab, out, nullptr, n, n, splits, stride, s); return; }
     const int gx = (n + 1023) / 1024;
     int gy = 1;                                            // split groups: enough workgroups to fill the chip

@@ -127,11 +127,6 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
     // cold HBM before the second arrives, and such half-line writes run at 3.8 TB/s against 4.6+ for whole lines (tools/micro/store_cold.hip).
     constexpr bool HOLDABLE = PAIR && std::is_same<TC, as_t>::value && MASK != AS_ALL && (MASK & AS_QKV) == 0;
     const bool hold = HOLDABLE && (ea.as_flags & 1) && !ea.n_valid;
-    // DEFER (with HOLD, three-stage ring, store-only epilogues): a pair's stores are issued at the START of the next even step, right behind
-    // that step's weight DMA instead of in front of it.  The VM counter retires in order, so the wait for a stage also waits for every
-    // store issued before that stage's DMA: issued behind the DMA, a pair has three to four column steps to be acknowledged instead of two.
-    constexpr bool DEFERABLE = HOLDABLE && COUNTED && R == 3;
-    const bool defer = DEFERABLE && hold && (ea.as_flags & 8);
     const bool nt_side = (ea.as_flags & 2) != 0;
 
     const int dbg = DBG ? ea.dbg : 0;          // ablation bits of tools/gemm_ablate.py, compiled out of the production kernels
@@ -296,35 +291,16 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
     }
 
     as_v8 held[RT], held_pre[RT];         // HOLD: the even step's packed groups (main output, saved pre-activation)
-    as_v8 held2[RT], held2_pre[RT];       // DEFER: the odd step's
 #pragma unroll
-    for (int i = 0; i < RT; ++i) { held[i] = as_v8{}; held_pre[i] = as_v8{}; held2[i] = as_v8{}; held2_pre[i] = as_v8{}; }
-    // stores of the pair of column steps that starts at column ncol (DEFER)
-    auto store_pair = [&](int ncol, bool both) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            if (!full && mw + 16 * i + c >= M) continue;
-            if constexpr ((MASK & AS_PREOUT) != 0) {
-                as_t* pp = reinterpret_cast<as_t*>(ea.pre_out) + eoff[i] + ncol;
-                as_st_pk(pp, held_pre[i], nt_side);
-                if (both) as_st_pk(pp + NS, held2_pre[i], nt_side);
-            }
-            as_t* cp = reinterpret_cast<as_t*>(C) + eoff[i] + ncol;
-            as_st_pk(cp, held[i], false);
-            if (both) as_st_pk(cp + NS, held2[i], false);
-        }
-    };
+    for (int i = 0; i < RT; ++i) { held[i] = as_v8{}; held_pre[i] = as_v8{}; }
     int slot = 0;
     for (int s = 0; s < nsteps; ++s) {
         // ---- T1: stage s has landed.  Younger operations that may stay in flight (in-order VM counter): the DMAs of
         // stages s+1 .. s+R-2 and, when the epilogue is a fixed number of stores and the row block is full, the stores
         // of the R-1 steps since its issue.
         if constexpr (COUNTED) {
-            if (full && !ea.n_valid && s >= R - 1 && s + R - 2 < nsteps && !(ea.as_flags & 4)) {      // bit 2 (experiment): every step waits for ALL its older stores
+            if (full && !ea.n_valid && s >= R - 1 && s + R - 2 < nsteps) {
                 if (!hold) as_wait_vm<(R - 2) * DPW + (R - 1) * OPS>();
-                // deferred pairs leave at the even steps BEHIND that step's DMA: younger than stage s's DMA are the other stage's DMA and
-                // exactly one pair (from s = 3 on; before that no pair has been stored yet)
-                else if (defer) { if (s >= 3) as_wait_vm<DPW + 2 * OPS>(); else as_wait_vm<0>(); }
                 // held stores leave in pairs at the odd steps: of the two steps since stage s was requested exactly one was odd (R = 3);
                 // with R = 2 only the step before this one counts — a pair when it was odd, nothing when it was even
                 else if constexpr (R == 3) as_wait_vm<DPW + 2 * OPS>();
@@ -352,9 +328,6 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
                 for (int q = 0; q < NG; ++q) au[i][q] = __builtin_nontemporal_load(reinterpret_cast<const as_u32x4*>(aux + eoff[i] + n0 + 4 * GW * q));      // last use of a saved pre-activation
         }
         if (s + R - 1 < nsteps && !(dbg & 8)) issue(slot == 0 ? (R - 1) * STAGE : slot - STAGE);
-        if constexpr (DEFERABLE) {
-            if (defer && !(s & 1) && s >= 2) store_pair(n0 - 2 * NS, true);
-        }
         // ---- MFMA: acc[j][i] = sum_k Bt[row(j), k] * A[16i + .., k]
         f32x4 acc[2][RT];
 #pragma unroll
@@ -436,8 +409,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
 #pragma unroll
                             for (int e = 0; e < 8; ++e) t[e] = (as_t)v[e];
                             as_t* pp = reinterpret_cast<as_t*>(ea.pre_out) + off;
-                            if (DEFERABLE && defer) { if (s & 1) held2_pre[i] = t; else held_pre[i] = t; }
-                            else if (s & 1) { as_st_pk(pp - NS, held_pre[i], nt_side); as_st_pk(pp, t, nt_side); }
+                            if (s & 1) { as_st_pk(pp - NS, held_pre[i], nt_side); as_st_pk(pp, t, nt_side); }
                             else if (s == nsteps - 1) as_st_pk(pp, t, nt_side);
                             else held_pre[i] = t;
                         } else as_st_nt<GW>(reinterpret_cast<TC*>(ea.pre_out) + off, v, nt_side);
@@ -483,8 +455,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
 #pragma unroll
                             for (int e = 0; e < 8; ++e) t[e] = (as_t)v[e];
                             as_t* cp = reinterpret_cast<as_t*>(C) + off;
-                            if (DEFERABLE && defer) { if (s & 1) held2[i] = t; else held[i] = t; }
-                            else if (s & 1) { as_st_pk(cp - NS, held[i], false); as_st_pk(cp, t, false); }
+                            if (s & 1) { as_st_pk(cp - NS, held[i], false); as_st_pk(cp, t, false); }
                             else if (s == nsteps - 1) as_st_pk(cp, t, false);
                             else held[i] = t;
                         } else as_st<GW>(C + off, v);
@@ -505,12 +476,6 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
             }
         }
         slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE;
-    }
-    if constexpr (DEFERABLE) {              // the last pair (or the single last step of an odd count)
-        if (defer) {
-            if (nsteps & 1) store_pair(nbase + (nsteps - 1) * NS, false);
-            else store_pair(nbase + (nsteps - 2) * NS, true);
-        }
     }
     // the prologue's transformed rows, for the backward pass: stored AFTER the column loop (the fragments are still in registers), so
     // that these stores do not sit in front of the loop's counted vmcnt waits and drain beside other workgroups' loops

@@ -67,6 +67,16 @@ int launch_gemm_nt(int dtA, int dtM, int dtC, int op, const void* A, const void*
 // dbias[Nb] += colsum(opB(B)) when dbias != nullptr.  slab = fp32 scratch of
 // gemm_tn_slab_floats(...) floats.
 size_t gemm_tn_slab_floats(int M, int Ka, int Nb, int dtM);
+// ---- batched, deferred column sums of partial rows (parameter gradients of LayerNorm / depthwise conv: ~45 launches of ~5 us per step, all off
+// the backward pass's dependency chain).  While a RedSink is installed (g_red_sink), launch_reduce_slabs / _slabs2 record the job instead of
+// launching; the caller keeps every recorded slab intact (a bump arena) until launch_reduce_flush sums all of them in ONE launch, each output element in a fixed
+// order (run-to-run bit-identical gradients; not the same order as the single launches).
+#define RED_MAXJOBS 48
+struct RedJob { const float* slab; float* out0; float* out1; size_t stride; int n0, n, splits, nb, nbv, first_block; };
+struct RedSink { RedJob job[RED_MAXJOBS]; int njobs = 0; int nblocks = 0; };
+extern RedSink* g_red_sink;
+bool reduce_sink_full();                                   // no room for another job: flush before the next deferring operator
+int launch_reduce_flush(RedSink* sink, hipStream_t s);
 bool gemm_tn_bias_rowscale_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, int T);   // the transposed-read kernel takes the call and T % 32 == 0
 // Deferred slab sums of the transposed-read wgrad kernel: with a TnDefer the launch writes slab[turn] (two caller-owned buffers of
 // gemm_tn_slab_floats floats each) and the sums of ITS slabs are carried by the next deferring launch as extra workgroups;

@@ -291,6 +291,15 @@ static void plan_workspace(ishara_model* m) {
     { size_t wf = 0; for (DenseW* w : m->denses) { const size_t f = gemm_tn_slab_floats((int)Mx, w->K, w->N, m->dt); if (f > wf) wf = f; }
       if (m->stem_kp) { const size_t f = gemm_tn_slab_floats((int)Mx, m->stem_kp, d, m->dt); if (f > wf) wf = f; }
       m->slab2[0] = m->f32(wf); m->slab2[1] = m->f32(wf); m->tn_defer_on = getenv("ISHARA_NO_DEFERRED_SLAB_SUMS") == nullptr; }
+    {   // arena of the deferred parameter-gradient sums: every LayerNorm / depthwise-conv backward of one pass (flushed early when it runs full)
+        size_t need = 0;
+        const size_t lnf = (layernorm_bwd_scratch_floats(d) + 63) & ~(size_t)63, dwf = (dwconv_bwd_scratch_floats(2 * maxw, 31) + 63) & ~(size_t)63;
+        need = (size_t)m->layers.size() * (5 * lnf + 2 * dwf);
+        const size_t cap = (size_t)256 << 20;                       // floats: 1 GiB
+        m->red_cap = need < cap ? need : cap;
+        m->red_on = getenv("ISHARA_NO_DEFERRED_REDUCE") == nullptr && m->red_cap > 0;
+        if (m->red_on) m->red_arena = m->f32(m->red_cap);
+    }
     m->ctcws = m->f32(ctc_workspace_floats(B, T, m->L));
     m->dlogits = m->f32(Mx * m->C);
     if (m->cls_pad) m->dlb = m->alloc(Mx * (size_t)m->cls_pad * 2);
@@ -478,6 +487,28 @@ int gemm_dgrad(ishara_model* m, const DenseW& w, const void* dY, int dtA, void* 
     CKP(m, gemm_nt_kernel_name(dtA, m->dt, m->dt, aop, dY, M, w.K, w.N, w.ldn, ea), by, 2.0 * M * w.N * w.K, launch_gemm_nt(dtA, m->dt, m->dt, aop, dY, m->ws + w.wn, dX, M, w.K, w.N, w.ldn, oa, ea, m->s));
     return 0;
 }
+// ---- deferred parameter-gradient sums (kernels.h RedSink): the LayerNorm / depthwise-conv backward operators leave their partial rows in a
+// bump arena instead of the shared slab, and ONE launch at the end of the backward pass (or when the arena / job table is full, or before a
+// gradient bucket is declared final) sums them all.  Off: ISHARA_NO_DEFERRED_REDUCE=1.
+int red_flush(ishara_model* m) {
+    if (m->red.njobs == 0) { m->red_off = 0; return 0; }
+    CKP(m, "reduce_jobs(deferred)", 0, 0, launch_reduce_flush(&m->red, m->s));
+    m->red_off = 0;
+    return 0;
+}
+static float* red_scratch(ishara_model* m, size_t floats) {
+    if (!m->red_on || floats > m->red_cap) return m->Wf(m->slab);
+    floats = (floats + 63) & ~(size_t)63;
+    if (m->red_off + floats > m->red_cap || reduce_sink_full()) { g_red_sink = nullptr; (void)red_flush(m); }
+    g_red_sink = &m->red;
+    float* p = m->Wf(m->red_arena) + m->red_off;
+    m->red_off += floats;
+    return p;
+}
+struct RedScope {      // the sink is installed by red_scratch (only for operators that got arena scratch) and removed when the launch returns
+    explicit RedScope(ishara_model*) {}
+    ~RedScope() { g_red_sink = nullptr; }
+};
 int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop, const OpArgs& oa, const void* dY, int dtB, int bop, const OpArgs& ob, int M, int ka_valid, int nb_valid,
                const float* bias_rowscale, int bias_T, const TnPsa* psa) {
     const double by = (double)M * w.K * dt_size(dtA) + (double)M * w.N * dt_size(dtB) + (double)w.K * w.N * 4;
@@ -739,10 +770,10 @@ static int conv_bwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x,
     // take the two-kernel path
     DwBnArgs bn; bn.h = m->W(cb.h2); bn.mean = m->Wf(cb.mean); bn.rstd = m->Wf(cb.rstd); bn.a = m->Wf(cb.a); bn.sg = m->Wf(cb.sg); bn.E = m->Wf(m->E); bn.Fc = m->Wf(m->Fc); bn.e_per_sample = 1;
     int fused = 0;
-    CKP(m, "dwconv_bwd", 10.0 * r.M * m->d * (double)dt_size(m->dt), 0, (fused = launch_dwconv_bwd_bn(dt, DWIN_SWISH, m->W(m->t1), bn, m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s)) < 0 ? fused : 0);
+    { RedScope red_scope_(m); CKP(m, "dwconv_bwd", 10.0 * r.M * m->d * (double)dt_size(m->dt), 0, (fused = launch_dwconv_bwd_bn(dt, DWIN_SWISH, m->W(m->t1), bn, m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, red_scratch(m, dwconv_bwd_scratch_floats(c, cb.k)), B, T, c, cb.k, cb.k - 1, m->s)) < 0 ? fused : 0); }
     if (!fused) {
         CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t1), m->W(cb.h2), m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.sg), m->Wf(m->E), 1, m->Wf(m->Fc), m->W(m->t1), B, T, c, m->s));
-        CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s));
+        { RedScope red_scope_(m); CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t1), m->W(cb.z1), m->P(cb.dw), m->W(m->t2), m->G(cb.dw), nullptr, red_scratch(m, dwconv_bwd_scratch_floats(c, cb.k)), B, T, c, cb.k, cb.k - 1, m->s)); }
     }
     EpiArgs e2; e2.resid = g;
     CK(gemm_dgrad(m, cb.W1, m->W(m->t2), dt, gn, r.M, OP_NONE, no, e2));
@@ -767,7 +798,7 @@ static int ffn_bwd(ishara_model* m, FFN& f, const Run& r, const void* x, const v
     EpiArgs e0;
     CK(gemm_dgrad(m, f.Wa, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));              // dxn
     CK(gemm_wgrad(m, f.Wa, m->W(f.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(f.mean), m->Wf(f.rstd), m->P(f.ln.gamma), g, gn, m->G(f.ln.gamma), m->G(f.ln.beta), m->Wf(m->slab), r.M, m->d, m->s));
+    { RedScope red_scope_(m); CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(f.mean), m->Wf(f.rstd), m->P(f.ln.gamma), g, gn, m->G(f.ln.gamma), m->G(f.ln.beta), red_scratch(m, layernorm_bwd_scratch_floats(m->d)), r.M, m->d, m->s)); }
     return 0;
 }
 
@@ -789,7 +820,7 @@ static int mhsa_bwd(ishara_model* m, MHSA& a, const Run& r, const void* x, const
                        r.B, m->H, m->T, m->dh, scale, dspec_attn(r, a.site_attn, a.rate), 1, m->cfg.attn_impl, attn_maskw(m, a.maskw), m->s));
     CK(gemm_dgrad(m, a.Wqkv, m->W(m->t2), dt, m->W(m->t1), r.M, OP_NONE, no, e0));            // dxn
     CK(gemm_wgrad(m, a.Wqkv, m->W(a.xn), dt, OP_NONE, no, m->W(m->t2), dt, OP_NONE, no, r.M));
-    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), m->Wf(m->slab), r.M, m->d, m->s));
+    { RedScope red_scope_(m); CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t1), x, m->Wf(a.mean), m->Wf(a.rstd), m->P(a.ln.gamma), g, gn, m->G(a.ln.gamma), m->G(a.ln.beta), red_scratch(m, layernorm_bwd_scratch_floats(m->d)), r.M, m->d, m->s)); }
     return 0;
 }
 
@@ -803,17 +834,17 @@ static int sqzconv_bwd(ishara_model* m, SqzConv& c, const Run& r, const void* x,
     EpiArgs e1; e1.dact = DACT_SWISH; e1.aux = m->W(c.zd);
     CK(gemm_dgrad(m, c.Wc3, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e1));                                // dzd
     CK(gemm_wgrad(m, c.Wc3, m->W(c.hd), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, m->Wf(m->slab), B, T, de, c.k, c.k - 1, m->s));   // dzc
+    { RedScope red_scope_(m); CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_SWISH, m->W(m->t2), m->W(c.zc), m->P(c.dw), m->W(m->t1), m->G(c.dw), nullptr, red_scratch(m, dwconv_bwd_scratch_floats(de, c.k)), B, T, de, c.k, c.k - 1, m->s)); }   // dzc
     CK(gemm_dgrad(m, c.Wc1, m->W(m->t1), dt, m->W(m->t2), r.M, OP_NONE, no, e0));                                // dxn
     CK(gemm_wgrad(m, c.Wc1, m->W(c.xn), dt, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
-    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(c.mean), m->Wf(c.rstd), m->P(c.ln.gamma), g, gn, m->G(c.ln.gamma), m->G(c.ln.beta), m->Wf(m->slab), r.M, d, m->s));
+    { RedScope red_scope_(m); CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, m->W(m->t2), x, m->Wf(c.mean), m->Wf(c.rstd), m->P(c.ln.gamma), g, gn, m->G(c.ln.gamma), m->G(c.ln.beta), red_scratch(m, layernorm_bwd_scratch_floats(m->d)), r.M, d, m->s)); }
     return 0;
 }
 
 int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, const void* g, void* gn) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no;
-    CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), m->Wf(m->slab), r.M, d, m->s));   // dr
+    { RedScope red_scope_(m); CKP(m, "layernorm_bwd", 4.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_layernorm_bwd(dt, g, m->W(c.r), m->Wf(c.lnmean), m->Wf(c.lnrstd), m->P(c.ln.gamma), nullptr, m->W(m->t1), m->G(c.ln.gamma), m->G(c.ln.beta), red_scratch(m, layernorm_bwd_scratch_floats(m->d)), r.M, d, m->s)); }   // dr
     const void* gs = m->W(m->t1);                          // gradient through the module's output dropout
     if (c.has_out_drop) {
         const DropSpec od = dspec(r, c.site_out, m->cfg.dropout_rate);
@@ -829,10 +860,10 @@ int confconv_bwd(ishara_model* m, ConfConv& c, const Run& r, const void* x, cons
     CKP(m, "bn_bwd_finalize", 0, 0, launch_bn_bwd_finalize(m->Wf(m->S1), m->Wf(m->S2), m->G(c.bn.gamma), m->G(c.bn.beta), m->Wf(m->Ecol), m->Wf(m->Fc), B, T, d, m->s));
     DwBnArgs bn; bn.h = m->W(c.v); bn.mean = m->Wf(c.mean); bn.rstd = m->Wf(c.rstd); bn.a = m->Wf(c.a); bn.E = m->Wf(m->Ecol); bn.Fc = m->Wf(m->Fc);
     int fused = 0;
-    CKP(m, "dwconv_bwd", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, (fused = launch_dwconv_bwd_bn(dt, DWIN_GLU, m->W(m->t2), bn, m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), c.dwb >= 0 ? m->G(c.dwb) : nullptr, m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s)) < 0 ? fused : 0);   // dg [M,2d]
+    { RedScope red_scope_(m); CKP(m, "dwconv_bwd", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, (fused = launch_dwconv_bwd_bn(dt, DWIN_GLU, m->W(m->t2), bn, m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), c.dwb >= 0 ? m->G(c.dwb) : nullptr, red_scratch(m, dwconv_bwd_scratch_floats(d, c.k)), B, T, d, c.k, (c.k - 1) / 2, m->s)) < 0 ? fused : 0); }   // dg [M,2d]
     if (!fused) {
         CKP(m, "bn_bwd_apply", 6.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_bn_bwd_apply(dt, m->W(m->t2), m->W(c.v), m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), nullptr, m->Wf(m->Ecol), 0, m->Wf(m->Fc), m->W(m->t2), B, T, d, m->s));   // dv
-        CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), c.dwb >= 0 ? m->G(c.dwb) : nullptr, m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));   // dg [M,2d]
+        { RedScope red_scope_(m); CKP(m, "dwconv_bwd", 8.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_bwd(dt, DWIN_GLU, m->W(m->t2), m->W(c.g), m->P(c.dw), m->W(m->t3), m->G(c.dw), c.dwb >= 0 ? m->G(c.dwb) : nullptr, red_scratch(m, dwconv_bwd_scratch_floats(d, c.k)), B, T, d, c.k, (c.k - 1) / 2, m->s)); }   // dg [M,2d]
     }
     EpiArgs e2; e2.resid = m->W(m->t1);
     CK(gemm_dgrad(m, c.Wp1, m->W(m->t3), dt, gn, r.M, OP_NONE, no, e2));
@@ -845,6 +876,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
     if (m->family != ISHARA_FAMILY_KERAS_HYBRID) { ishara_set_error("ishara_loss_backward: this handle is an encoder-only family; use ishara_encoder_backward"); return -1; }
     if (B != m->lastB || !m->last_training) { ishara_set_error("ishara_loss_backward: call ishara_forward(training=1) with the same batch first"); return -1; }
     m->s = (hipStream_t)st;
+    m->red.njobs = 0; m->red.nblocks = 0; m->red_off = 0; g_red_sink = nullptr;       // ... nor recorded column sums
     m->tn_defer.pending = false;        // a previous backward pass that returned early (error path) must not leave slab sums behind for this one to add
     Run r{B, B * m->T, 1, m->last_seed};
     const int dt = m->dt, d = m->d, T = m->T;
@@ -896,7 +928,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
             STEP(ffn_bwd(m, cb.ffn1, r, lin, g, gn));
         }
 #undef STEP
-        if (!m->bucket_ev.empty() && m->bucket_after_layer[li] >= 0) { CK(wgrad_flush(m)); HIP_CHECK_RET(hipEventRecord(m->bucket_ev[m->bucket_after_layer[li]], m->s)); }
+        if (!m->bucket_ev.empty() && m->bucket_after_layer[li] >= 0) { CK(wgrad_flush(m)); CK(red_flush(m)); HIP_CHECK_RET(hipEventRecord(m->bucket_ev[m->bucket_after_layer[li]], m->s)); }
     }
     // ---- stem
     CKP(m, "sample_reduce", 2.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_sample_reduce(dt, g, m->W(m->stem_h0), m->Wf(m->stem_mean), m->Wf(m->stem_rstd), m->Wf(m->S1), m->Wf(m->S2), B, T, d, m->s));
@@ -908,6 +940,7 @@ extern "C" int ishara_loss_backward(ishara_model* m, const float* logits, const 
     } else
         CK(gemm_wgrad(m, m->stemW, m->last_x, DT_F32, OP_NONE, no, m->W(m->t1), dt, OP_NONE, no, r.M));
     CK(wgrad_flush(m));
+    CK(red_flush(m));
     if (!m->bucket_ev.empty()) HIP_CHECK_RET(hipEventRecord(m->bucket_ev.back(), m->s));
     return 0;
 }

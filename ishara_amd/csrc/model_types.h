@@ -122,6 +122,7 @@ struct ishara_model {
     uint32_t nsites = 0;
     std::vector<DenseW*> denses;
     // temps
+    RedSink red; Buf red_arena; size_t red_cap = 0, red_off = 0; bool red_on = false;      // deferred column sums of LayerNorm / depthwise-conv parameter gradients (model.hip red_scratch)
     TnDefer tn_defer; Buf slab2[2]; bool tn_defer_on = false;      // deferred wgrad slab sums (gemm.hip): two alternating slab buffers
     Buf gA, gB, t1, t2, t3, S1, S2, E, Fc, Ecol, ecap, dse, dgapT, slab, ctcws, dlogits, nllb, delta;
     Buf psaG, psaR; bool psa_on = false;   // TnPsa outputs: G [B, d], Rpart [B][d / 64][2d]
