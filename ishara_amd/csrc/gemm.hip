@@ -1765,6 +1765,10 @@ bool reduce_sink_full() { return g_red_sink && g_red_sink->njobs >= RED_MAXJOBS 
 static bool reduce_sink_take(const float* slab, float* out0, float* out1, int n0, int n, int splits, size_t stride, int nb, int nbv) {
     RedSink* k = g_red_sink;
     if (!k || k->njobs >= RED_MAXJOBS || !reduce_cols_ok(slab, out0, out1, n0, n, stride)) return false;
+    // two jobs into the same parameter (the Conformer block's shared layer_norm1 is differentiated twice) would add to it from two workgroups
+    // of the one launch: the later one is launched on its own right away, the batch follows in stream order (two ordered adds)
+    for (int i = 0; i < k->njobs; ++i)
+        if (k->job[i].out0 == out0 || (out1 && k->job[i].out1 == out1) || (out1 && k->job[i].out0 == out1) || k->job[i].out1 == out0) return false;
     RedJob& J = k->job[k->njobs++];
     J.slab = slab; J.out0 = out0; J.out1 = out1; J.stride = stride; J.n0 = n0; J.n = n; J.splits = splits; J.nb = nb; J.nbv = nbv;
     J.first_block = k->nblocks;
