@@ -13,7 +13,7 @@ N>1: run under `python -m torch.distributed.run --nproc-per-node N ...` (one ran
 that launcher, bench.py starts it itself as a child process and relays rank 0's JSON line and the exit code.  A mismatch
 between --gpus and the ranks torch.distributed sees is an error, never a silent 1-GPU run.
 
---config 4: BASELINE configs[3] (d512, 6+6 blocks, 8 heads, T512) training throughput, B=64 per GPU.
+--config 4: BASELINE configs[3] (d512, 6+6 blocks, 8 heads, T512) training throughput, B=512 per GPU.
 --config 5: BASELINE configs[4] (inference, B=1, T=384, fp16 storage, hipGraph replay): metric = latency per clip.
 
 Rank 0 prints ONE JSON line (contract in the task brief) with two extra objects:
@@ -44,7 +44,7 @@ CONFIGS = {
             train_bytes_per_frame=373e3, train_flops_per_frame=49.7e6),
     4: dict(kw=dict(dim=512, num_conv_squeeze_blocks=6, num_conv_conform_blocks=6, kernel_sizes=[11, 5, 3], num_conv_per_block=3,
                     dropout_rate=0.2, num_heads=8, expansion_factor=2, transformer_kernel_size=15, input_shape=(512, 224)),
-            batch=64, metric="landmark-frames/sec training (B=64,T=512,d=512, 6+6 blocks)",
+            batch=512, metric="landmark-frames/sec training (B=512,T=512,d=512, 6+6 blocks)",      # B: SURVEY §8(d) "as large as fits" — 512 (workspace ~160 GiB of 288); 768 also fits (+1.3 % frames/s), 64 / 128 / 256 give 0.85 / 0.90 / 0.97 of its rate
             workload="configs[3]: get_model(dim=512, 6 squeeze + 6 conformer blocks, 8 heads) T=512 CTC train step "
                      "(fwd+CTC+bwd+RAdam/Lookahead, dropout on)",
             train_bytes_per_frame=2.18e6, train_flops_per_frame=563.2e6),
@@ -233,7 +233,7 @@ def run_training(args):
         "kernels_ms": {k: round(v["ms"], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg["kw"], 8 if args.config == 2 else 2, 12 if args.config == 2 else 4)
+        out["cpu_baseline"] = cpu_baseline(cfg["kw"], 8 if args.config == 2 else 2, 12 if args.config == 2 else 3)
     print(json.dumps(out))
 
 

@@ -213,33 +213,49 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     // ---- phase 3: state posteriors -> class posteriors by LDS scatter-add (one frame per wave at a time: O(T*S) work;
     // a (frame, class) thread looping over the states was O(T*C*S) and took longer than both recursions), then the gradient
     if (dlogits) {
-        __shared__ float cls[4][64];
+        // four frames of a wave in flight together: the loop used to wait out one L2 round trip per frame (96 dependent trips per wave)
+        constexpr int U = 4;
+        __shared__ float cls[4][U][64];
         const double logp = s_logp;
         float* dl = dlogits + (size_t)b * Tn * C;
         const int wv = tid >> 6;
-        for (int t = wv; t < Tn; t += 4) {
-            cls[wv][lane] = 0.f;
-            const double* ga = Gw + (size_t)t * SP;
-            const double* gb = Hw + (size_t)t * SP;
+        for (int t0 = wv; t0 < Tn; t0 += 4 * U) {
+            double al[U][NS], bs[U][NS];
+            float lgv[U];
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int s = lane + 64 * k;                  // strided: coalesced 512-byte reads of the lattice rows
-                if (s < S) {
-                    const double al = ga[s], bs = gb[s];
-                    if (al > -1e29 && bs > -1e29 && logp > -1e29) atomicAdd(&cls[wv][ext[s]], __expf((float)(al + bs - logp)));
+            for (int u = 0; u < U; ++u) {
+                const int t = min(t0 + 4 * u, Tn - 1);
+                cls[wv][u][lane] = 0.f;
+                const double* ga = Gw + (size_t)t * SP;
+                const double* gb = Hw + (size_t)t * SP;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int s = lane + 64 * k;              // strided: coalesced 512-byte reads of the lattice rows
+                    al[u][k] = s < S ? ga[s] : CTC_NEG; bs[u][k] = s < S ? gb[s] : CTC_NEG;
                 }
+                lgv[u] = lane < C ? lg[(size_t)t * C + lane] : 0.f;
             }
-            float gv = 0.f;
-            if (lane < C) {
-                const float sm = expf(lg[(size_t)t * C + lane] - lse[t]);
-                gv = grad_scale * (sm - cls[wv][lane]);
-                dl[(size_t)t * C + lane] = gv;
-            }
-            if (dlb) {      // bf16 copy of the row, zero padded to 128 classes (MFMA operand of the classifier's dgrad / wgrad)
-                const float lo = __shfl(gv, (2 * lane) & 63, 64), hi = __shfl(gv, (2 * lane + 1) & 63, 64);
-                typedef __attribute__((ext_vector_type(2))) __bf16 ctc_bf2;
-                ctc_bf2 pk; pk[0] = (__bf16)(lane < 32 ? lo : 0.f); pk[1] = (__bf16)(lane < 32 ? hi : 0.f);
-                dlb[((size_t)b * Tn + t) * 64 + lane] = __builtin_bit_cast(uint32_t, pk);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + 4 * u;
+                if (t >= Tn) continue;                        // wave-uniform
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int s = lane + 64 * k;
+                    if (s < S && al[u][k] > -1e29 && bs[u][k] > -1e29 && logp > -1e29) atomicAdd(&cls[wv][u][ext[s]], __expf((float)(al[u][k] + bs[u][k] - logp)));
+                }
+                float gv = 0.f;
+                if (lane < C) {
+                    const float sm = expf(lgv[u] - lse[t]);
+                    gv = grad_scale * (sm - cls[wv][u][lane]);
+                    dl[(size_t)t * C + lane] = gv;
+                }
+                if (dlb) {      // bf16 copy of the row, zero padded to 128 classes (MFMA operand of the classifier's dgrad / wgrad)
+                    const float lo = __shfl(gv, (2 * lane) & 63, 64), hi = __shfl(gv, (2 * lane + 1) & 63, 64);
+                    typedef __attribute__((ext_vector_type(2))) __bf16 ctc_bf2;
+                    ctc_bf2 pk; pk[0] = (__bf16)(lane < 32 ? lo : 0.f); pk[1] = (__bf16)(lane < 32 ? hi : 0.f);
+                    dlb[((size_t)b * Tn + t) * 64 + lane] = __builtin_bit_cast(uint32_t, pk);
+                }
             }
         }
     }

@@ -53,8 +53,8 @@ template <typename T> DEVI void dw_bn_row(DwRow<T>& d, const DwRow<T>& h, const 
 DEVI void dw_store4(bf16* p, dwf2 lo, dwf2 hi) { const float v[4] = {lo.x, lo.y, hi.x, hi.y}; store4(p, v); }
 DEVI void dw_store4(float* p, dwf2 lo, dwf2 hi) { *reinterpret_cast<float4*>(p) = make_float4(lo.x, lo.y, hi.x, hi.y); }
 
-template <int K, bool BN = false> struct DwCfg {
-    static constexpr int LB = K <= 5 ? K : 4;   // steps whose loads are in flight together
+template <int K, bool BN = false, int LBX = 0> struct DwCfg {
+    static constexpr int LB = LBX ? LBX : (K <= 5 ? K : 4);   // steps whose loads are in flight together (LBX: experiment override, ISHARA_DW_LB)
     static constexpr int WPS = K >= 11 ? 2 : (K >= 5 ? 3 : 4);  // waves per SIMD the register budget allows
 };
 
@@ -62,12 +62,12 @@ template <int K, bool BN = false> struct DwCfg {
 // pointer) is wave-uniform and is kept in scalar registers -> scalar loop control instead of exec-mask branches per step
 // BN: dy is the gradient of a BatchNorm OUTPUT; the BatchNorm backward (bn.h = the BatchNorm input = this conv's forward output)
 // is applied to every dy row on its way into the window, so the [M, C] gradient of the conv output never exists in memory
-template <typename T, int K, int INOP, bool WU, bool BN>
+template <typename T, int K, int INOP, bool WU, bool BN, int LBX = 0>
 __global__ __launch_bounds__(256, (DwCfg<K, BN>::WPS)) void dwconv_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ w,
                                                                             T* __restrict__ dx, float* __restrict__ part,
                                                                             int B, int Tn, int C, int padl, int seg_len, DwBnArgs bn) {
     extern __shared__ float red[];             // (K+1)*C block accumulator
-    constexpr int LB = DwCfg<K, BN>::LB;
+    constexpr int LB = DwCfg<K, BN, LBX>::LB;
     const int tid = threadIdx.x;
     const int cg = C >> 2, lanes = 256 / cg;
     const int c4 = tid % cg;
@@ -234,7 +234,10 @@ static int run_dw_fused(int inop, const T* dy, const T* x, const float* w, T* dx
     if (grid > max_rows) grid = max_rows;
     if (grid > 512) grid = 512;
     const size_t sh = (size_t)(k + 1) * C * sizeof(float);
-#define DWF2(KK, OP, WUU, BNN) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, WUU, BNN>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len, bn)
+    static const int lbx = getenv("ISHARA_DW_LB") ? atoi(getenv("ISHARA_DW_LB")) : 0;      // experiment: rows in flight per group at K >= 11 (6 or 8; default 4)
+#define DWF2(KK, OP, WUU, BNN) do { if (KK >= 11 && lbx == 6) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, WUU, BNN, (KK >= 11 ? 6 : 0)>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len, bn); \
+    else if (KK >= 11 && lbx == 8) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, WUU, BNN, (KK >= 11 ? 8 : 0)>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len, bn); \
+    else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, WUU, BNN>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len, bn); } while (0)
 #define DWF(KK, OP) do { if (bn.h) { if (cg % 64 == 0) DWF2(KK, OP, true, true); else DWF2(KK, OP, false, true); } \
                          else { if (cg % 64 == 0) DWF2(KK, OP, true, false); else DWF2(KK, OP, false, false); } } while (0)
 #define DWFK(OP) switch (k) { case 3: DWF(3, OP); break; case 5: DWF(5, OP); break; case 11: if constexpr (is_bf16_t<T>::value) { DWF(11, OP); } break; \
