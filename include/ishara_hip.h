@@ -182,6 +182,12 @@ int ishara_op_layernorm_bwd(int32_t dt, const void* dy, const void* x, const flo
 int ishara_op_dwconv_fwd(int32_t dt, int32_t inop, const void* x, const float* w, const float* bias, void* y,
                          float* ssum, float* ssq, int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl,
                          ishara_stream s);
+/* the same with caller scratch (ishara_op_dwconv_fwd_scratch_bytes) for the statistics: per-workgroup partial rows summed in a fixed order, no
+ * float atomics — the path the model itself takes */
+int64_t ishara_op_dwconv_fwd_scratch_bytes(int32_t B, int32_t T, int32_t C);
+int ishara_op_dwconv_fwd_ex(int32_t dt, int32_t inop, const void* x, const float* w, const float* bias, void* y,
+                            float* ssum, float* ssq, void* scratch, int32_t B, int32_t T, int32_t C, int32_t k,
+                            int32_t padl, ishara_stream s);
 int64_t ishara_op_dwconv_scratch_bytes(int32_t C, int32_t k);
 /* scratch: ishara_op_dwconv_scratch_bytes(C,k) bytes, or NULL (atomic weight-grad path) */
 int ishara_op_dwconv_bwd(int32_t dt, int32_t inop, const void* dy, const void* x, const float* w, void* dx,

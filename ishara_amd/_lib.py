@@ -77,6 +77,8 @@ SIGNATURES = {
     "ishara_op_layernorm_bwd": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ishara_op_dwconv_fwd": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "ishara_op_dwconv_scratch_bytes": (_I64, [_I32, _I32]),
+    "ishara_op_dwconv_fwd_scratch_bytes": (_I64, [_I32, _I32, _I32]),
+    "ishara_op_dwconv_fwd_ex": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "ishara_op_dwconv_bwd": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "ishara_op_attn_scratch_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "ishara_op_attn_fwd": (C.c_int, [_I32, _P, _P, _I32, _I32, _I32, _I32, _F, _U32, _U32, _F, _I32, _P, _P]),

@@ -54,7 +54,7 @@ DEVI void dw_store4(bf16* p, dwf2 lo, dwf2 hi) { const float v[4] = {lo.x, lo.y,
 DEVI void dw_store4(float* p, dwf2 lo, dwf2 hi) { *reinterpret_cast<float4*>(p) = make_float4(lo.x, lo.y, hi.x, hi.y); }
 
 template <int K, bool BN = false, int LBX = 0> struct DwCfg {
-    static constexpr int LB = LBX ? LBX : (K <= 5 ? K : 4);   // steps whose loads are in flight together (LBX: experiment override, ISHARA_DW_LB)
+    static constexpr int LB = LBX ? LBX : (K <= 5 ? K : 4);   // steps whose loads are in flight together (LBX: override; K = 11 runs with 8 — 1.355 -> 1.298 ms of depthwise backward per step at config #2, LB 6: 1.338)
     static constexpr int WPS = K >= 11 ? 2 : (K >= 5 ? 3 : 4);  // waves per SIMD the register budget allows
 };
 
@@ -234,7 +234,7 @@ static int run_dw_fused(int inop, const T* dy, const T* x, const float* w, T* dx
     if (grid > max_rows) grid = max_rows;
     if (grid > 512) grid = 512;
     const size_t sh = (size_t)(k + 1) * C * sizeof(float);
-    static const int lbx = getenv("ISHARA_DW_LB") ? atoi(getenv("ISHARA_DW_LB")) : 0;      // experiment: rows in flight per group at K >= 11 (6 or 8; default 4)
+    static const int lbx = getenv("ISHARA_DW_LB") ? atoi(getenv("ISHARA_DW_LB")) : 8;      // rows in flight per group at K >= 11: 8 (A/B: ISHARA_DW_LB=4 / 6)
 #define DWF2(KK, OP, WUU, BNN) do { if (KK >= 11 && lbx == 6) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, WUU, BNN, (KK >= 11 ? 6 : 0)>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len, bn); \
     else if (KK >= 11 && lbx == 8) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, WUU, BNN, (KK >= 11 ? 8 : 0)>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len, bn); \
     else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<T, KK, OP, WUU, BNN>), dim3(grid), dim3(256), sh, s, dy, x, w, dx, part, B, Tn, C, padl, seg_len, bn); } while (0)

@@ -757,6 +757,166 @@ __global__ __launch_bounds__(256) void dwconv_reg8_kernel(const T* __restrict__ 
         }
     }
 }
+
+// ---- forward, K = 11 / 15 (the first Conv1DBlock of a group, the transformer blocks' conv modules): a STREAMING LDS kernel.
+// The 64 x 128 tile kernel above re-stages a (64 + K - 1)-row tile per workgroup (23 % halo at K = 15), runs load -> barrier -> compute -> store
+// strictly in sequence inside a workgroup, and stores 8 bytes per lane: 2.6 TB/s at K = 11.  Here a workgroup owns 128 channels of ONE sample for
+// a whole time range and walks it in 32-row chunks through a 64-row LDS ring of TRANSFORMED inputs (fp32, Swish / GLU applied once per element):
+//   * no halo re-reads inside a range, the tap weights (K x 4 channels per thread) are loaded once per workgroup;
+//   * the next chunk's global loads are in flight while the current chunk is computed (two barriers per chunk);
+//   * thread = 4 channels x 4 consecutive rows, row-stationary accumulation (every ring row is read once per thread and feeds up to four outputs);
+//   * lane pairs swap halves (DPP quad_perm) so that every store is 16 bytes: an even lane writes 8 channels of rows 0 / 2, an odd lane of rows 1 / 3;
+//   * BatchNorm / GAP statistics: per-thread sums over the whole range, one partial row per workgroup at the end (deterministic, as before).
+// Non-causal convolutions (padl < K - 1) compute output row t when input row t + K - 1 - padl is in the ring: the output window lags the input
+// window by `lag` rows and one more (input-free) chunk drains it.
+template <typename T, int K, int INOP>
+__global__ __launch_bounds__(256, 3) void dwconv_stream_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                             T* __restrict__ y, int Tn, int C, int padl, float* __restrict__ part, int tsplit) {
+    constexpr int RB = 64, CH = 32, CT = 128;           // ring rows, chunk rows, channels per workgroup
+    __shared__ __attribute__((aligned(16))) float ring[RB * CT];
+    __shared__ float sred[8][2][CT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int c0 = blockIdx.x * CT, b = blockIdx.y;
+    const int Cin = (INOP == DWIN_GLU) ? 2 * C : C;
+    const int lag = K - 1 - padl;
+    // time range of this workgroup (tsplit ranges per sample, multiples of CH rows)
+    const int per = ((Tn + tsplit - 1) / tsplit + CH - 1) / CH * CH;
+    const int r_beg = blockIdx.z * per, r_end = min(Tn, r_beg + per);
+    if (r_beg >= Tn) return;
+    // ---- compute mapping: 32 channel quads x 8 row groups of 4
+    const int cq = tid & 31, rg = tid >> 5;
+    const int ch = c0 + cq * 4;
+    float wr[K][4];
+#pragma unroll
+    for (int j = 0; j < K; ++j) load4(w + (size_t)j * C + ch, wr[j]);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) load4(bias + ch, bv);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- staging mapping: 16 chunks of 8 channels x 16 rows, two row sets per chunk of 32 rows
+    const int sc = tid & 15, sr = tid >> 4;
+    typedef __attribute__((ext_vector_type(4))) uint32_t raw4;
+    raw4 rv[2], rgl[2];
+    auto gload = [&](int t0, bool hi_only = false) {           // input rows t0 .. t0+31 (zero outside [0, Tn); hi_only: rows t0+16 .. only — the K - 1 <= 14 history rows)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + sr + 16 * h;
+            rv[h] = raw4{0u, 0u, 0u, 0u}; rgl[h] = raw4{0u, 0u, 0u, 0u};
+            if (t >= 0 && t < Tn && (h == 1 || !hi_only)) {
+                const T* p = x + ((size_t)b * Tn + t) * Cin + c0 + sc * 8;
+                rv[h] = *reinterpret_cast<const raw4*>(p);
+                if (INOP == DWIN_GLU) rgl[h] = *reinterpret_cast<const raw4*>(p + C);
+            }
+        }
+    };
+    auto lstore = [&](int t0) {          // transform once, fp32 into the ring slot of the row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = t0 + sr + 16 * h;
+            float v[8];
+            { T tmp[8]; *reinterpret_cast<raw4*>(tmp) = rv[h];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = to_f(tmp[e]); }
+            if (INOP == DWIN_SWISH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = swishf_(v[e]);
+            } else if (INOP == DWIN_GLU) {
+                T tg[8]; *reinterpret_cast<raw4*>(tg) = rgl[h];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= sigmoidf_(to_f(tg[e]));
+            }
+            if (t < 0 || t >= Tn) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            float* dst = ring + ((t & (RB - 1)) * CT) + sc * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    };
+    // prologue: the history rows [in0 - CH, in0) (zeros before the sample / real rows when a range starts inside it) and the first chunk
+    const int in0 = (r_beg + lag) / CH * CH;            // output row t is computed by the chunk that brings input row t + lag
+    gload(in0 - CH, true); lstore(in0 - CH);
+    gload(in0); lstore(in0);
+    __syncthreads();
+    // chunk i: inputs [ti, ti + CH) are in the ring; outputs [ti - lag, ti + CH - lag) clipped to [r_beg, r_end)
+    for (int ti = in0; ti - lag < r_end; ti += CH) {
+        const bool more = ti + CH - lag < r_end;
+        if (more) gload(ti + CH);
+        const int o0 = ti - lag + rg * 4;                 // first output row of this thread
+        float acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[u][e] = 0.f;
+        // input rows o0 - padl .. o0 - padl + K + 2
+#pragma unroll
+        for (int qd = 0; qd < K + 3; ++qd) {
+            const int tin = o0 - padl + qd;
+            const float4 rw = *reinterpret_cast<const float4*>(ring + ((tin & (RB - 1)) * CT) + cq * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = qd - u;
+                if (j >= 0 && j < K) { acc[u][0] += wr[j][0] * rw.x; acc[u][1] += wr[j][1] * rw.y; acc[u][2] += wr[j][2] * rw.z; acc[u][3] += wr[j][3] * rw.w; }
+            }
+        }
+        // pack, swap halves inside lane pairs, 16-byte stores
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = o0 + u >= r_beg && o0 + u < r_end;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[u][e] += bv[e]; if (live) { s1[e] += acc[u][e]; s2[e] += acc[u][e] * acc[u][e]; } }
+            T tmp[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tmp[e] = from_f<T>(acc[u][e]);
+            pk[u][0] = reinterpret_cast<const uint32_t*>(tmp)[0]; pk[u][1] = reinterpret_cast<const uint32_t*>(tmp)[1];
+        }
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // even lane keeps rows 2h (own low half | partner's half), odd lane rows 2h + 1 (partner's half | own high half)
+            const int mine = 2 * h + (odd ? 1 : 0), theirs = 2 * h + (odd ? 0 : 1);
+            uint32_t give0 = pk[theirs][0], give1 = pk[theirs][1];
+            const uint32_t got0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give0, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+            const uint32_t got1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give1, 0xB1, 0xf, 0xf, true);
+            const int t = o0 + mine;
+            if (t >= r_beg && t < r_end) {
+                raw4 o = odd ? raw4{got0, got1, pk[mine][0], pk[mine][1]} : raw4{pk[mine][0], pk[mine][1], got0, got1};
+                *reinterpret_cast<raw4*>(y + ((size_t)b * Tn + t) * C + c0 + (cq >> 1) * 8) = o;
+            }
+        }
+        __syncthreads();                 // every thread is done reading the rows the next chunk overwrites
+        if (more) lstore(ti + CH);
+        __syncthreads();
+    }
+    if (part) {      // one partial row per (sample, time range): part[B][P = tsplit][2][C]
+        sred[rg][0][cq * 4 + 0] = s1[0]; sred[rg][0][cq * 4 + 1] = s1[1]; sred[rg][0][cq * 4 + 2] = s1[2]; sred[rg][0][cq * 4 + 3] = s1[3];
+        sred[rg][1][cq * 4 + 0] = s2[0]; sred[rg][1][cq * 4 + 1] = s2[1]; sred[rg][1][cq * 4 + 2] = s2[2]; sred[rg][1][cq * 4 + 3] = s2[3];
+        __syncthreads();
+        if (tid < CT) {
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { a += sred[r][0][tid]; q += sred[r][1][tid]; }
+            float* pr = part + (((size_t)b * gridDim.z + blockIdx.z) * 2) * C + c0 + tid;
+            pr[0] = a; pr[C] = q;
+        }
+    }
+}
+static bool dw_stream_ok(int dt, int C, int k, int T) { return dt != DT_F32 && (k == 11 || k == 15) && C % 128 == 0 && T >= 64; }
+template <typename T>
+static int launch_dw_stream(int k, const T* x, const float* w, const float* bias, T* y, int B, int Tn, int C, int padl, int inop, float* part, hipStream_t s) {
+    // enough workgroups for ~3 rounds of the chip's 768-1024 slots, whole 32-row chunks per range
+    int tsplit = 1;
+    while ((C / 128) * B * tsplit < 2048 && Tn / (tsplit * 2) >= 128) tsplit *= 2;      // every extra range re-reads 16 history rows
+    const dim3 grid(C / 128, B, tsplit);
+#define DWS(KK, OP) hipLaunchKernelGGL((dwconv_stream_kernel<T, KK, OP>), grid, dim3(256), 0, s, x, w, bias, y, Tn, C, padl, part, tsplit)
+#define DWSK(OP) do { if (k == 11) DWS(11, OP); else DWS(15, OP); } while (0)
+    if (inop == DWIN_SWISH) DWSK(DWIN_SWISH); else if (inop == DWIN_GLU) DWSK(DWIN_GLU); else DWSK(DWIN_NONE);
+#undef DWSK
+#undef DWS
+    return tsplit;      // partial rows per sample
+}
+
 // applicable: 16-bit storage, K in {3, 5}, C/8 in {32, 64, 128, 256}
 static bool dw_reg8_ok(int dt, int C, int k) { return dt != DT_F32 && (k == 3 || k == 5) && C % 8 == 0 && C / 8 >= 32 && C / 8 <= 256 && 256 % (C / 8) == 0; }
 template <typename T>
@@ -833,7 +993,11 @@ int launch_dwconv_fwd(int dt, int inop, const void* x, const float* w, const flo
     if (dwconv_check(C, k)) return -1;
     if (!colsum) part = nullptr;
     int P;
-    if (dw_reg8_ok(dt, C, k) && !g_force_dw_lds && (part || !colsum)) {          // statistics only through the deterministic partial rows
+    static const bool no_stream = getenv("ISHARA_NO_DW_STREAM") != nullptr;      // A/B switch: the 64 x 128 tile kernel instead
+    if (dw_stream_ok(dt, C, k, T) && B > DW_SMALL_B && !g_force_dw_lds && !no_stream && (part || !colsum)) {
+        if (dt == DT_BF16) P = launch_dw_stream<bf16>(k, (const bf16*)x, w, bias, (bf16*)y, B, T, C, padl, inop, colsum ? part : nullptr, s);
+        else P = launch_dw_stream<f16>(k, (const f16*)x, w, bias, (f16*)y, B, T, C, padl, inop, colsum ? part : nullptr, s);
+    } else if (dw_reg8_ok(dt, C, k) && !g_force_dw_lds && (part || !colsum)) {          // statistics only through the deterministic partial rows
         if (dt == DT_BF16) P = launch_dw_reg8<bf16>(k, (const bf16*)x, w, bias, (bf16*)y, B, T, C, padl, inop, colsum ? part : nullptr, s);
         else P = launch_dw_reg8<f16>(k, (const f16*)x, w, bias, (f16*)y, B, T, C, padl, inop, colsum ? part : nullptr, s);
     } else if (dw_reg_ok(C, k) && !g_force_dw_lds) {

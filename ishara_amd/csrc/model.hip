@@ -1111,6 +1111,13 @@ extern "C" int ishara_op_dwconv_fwd(int32_t dt, int32_t inop, const void* x, con
                                     int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {
     return launch_dwconv_fwd(dt, inop, x, w, bias, y, ssum, ssq, nullptr, B, T, C, k, padl, (hipStream_t)s);
 }
+// the same with caller scratch for the deterministic statistics (partial rows summed in a fixed order): the path the model takes, and the
+// only one that reaches the streaming K = 11 / 15 kernel at B > 8
+extern "C" int64_t ishara_op_dwconv_fwd_scratch_bytes(int32_t B, int32_t T, int32_t C) { return (int64_t)(dwconv_fwd_scratch_floats(B, T, C) * sizeof(float)); }
+extern "C" int ishara_op_dwconv_fwd_ex(int32_t dt, int32_t inop, const void* x, const float* w, const float* bias, void* y, float* ssum, float* ssq,
+                                       void* scratch, int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {
+    return launch_dwconv_fwd(dt, inop, x, w, bias, y, ssum, ssq, (float*)scratch, B, T, C, k, padl, (hipStream_t)s);
+}
 extern "C" int64_t ishara_op_dwconv_scratch_bytes(int32_t C, int32_t k) { return (int64_t)(dwconv_bwd_scratch_floats(C, k) * sizeof(float)); }
 extern "C" int ishara_op_dwconv_bwd(int32_t dt, int32_t inop, const void* dy, const void* x, const float* w, void* dx, float* dw, float* dbias,
                                     void* scratch, int32_t B, int32_t T, int32_t C, int32_t k, int32_t padl, ishara_stream s) {

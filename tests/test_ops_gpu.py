@@ -187,6 +187,45 @@ def _dwconv(lib, dt, B, T, Cc, k, inop, causal, variant):
         close(dbias, br.grad, "dw_dbias", rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * (B * T) ** 0.5)
 
 
+@pytest.mark.parametrize("dt", ["bf16"])
+@pytest.mark.parametrize("B,T,Cc,k,inop,causal", [(9, 384, 512, 11, 1, True), (9, 384, 512, 15, 1, True), (10, 384, 256, 15, 2, False), (9, 200, 128, 11, 0, True),
+                                                 (12, 72, 128, 15, 2, False), (9, 512, 1024, 11, 1, True)])
+def test_dwconv_streaming_forward(lib, dt, B, T, Cc, k, inop, causal):
+    """The streaming K = 11 / 15 forward kernel (elementwise.hip dwconv_stream_kernel: 64-row LDS ring per 128 channels, lane-pair 16-byte
+    stores, time ranges per sample) — reached only with caller scratch and more than 8 samples, i.e. the model's own call: outputs and the
+    per-sample statistics against the fp64 reference, causal and 'same' padding, ragged T (partial last chunk, ranges that do not divide T),
+    GLU input (2C channels) and bias; and bit-identical outputs to the tile kernel it replaces wherever both apply."""
+    code, tdt = DT[dt]
+    g = torch.Generator().manual_seed(T + k + Cc)
+    Cin = 2 * Cc if inop == 2 else Cc
+    x = torch.randn(B, T, Cin, generator=g).to(tdt)
+    w = torch.randn(k, Cc, generator=g) / k ** 0.5
+    bias = torch.randn(Cc, generator=g) if not causal else None
+    padl = k - 1 if causal else (k - 1) // 2
+    xd, wd = x.cuda(), dev(w)
+    bd = dev(bias) if bias is not None else None
+    y = torch.empty(B, T, Cc, dtype=tdt, device="cuda")
+    ssum, ssq = torch.zeros(B, Cc, device="cuda"), torch.zeros(B, Cc, device="cuda")
+    sc = torch.empty(int(lib.ishara_op_dwconv_fwd_scratch_bytes(B, T, Cc)) + 256, dtype=torch.uint8, device="cuda")
+    scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    _lib.check(lib.ishara_op_dwconv_fwd_ex(code, inop, _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), _lib.ptr(ssum), _lib.ptr(ssq), scp, B, T, Cc, k, padl, stream()))
+    ref = _dw_ref(x.double(), w.double(), bias.double() if bias is not None else None, inop, padl, Cc)
+    close(y, ref, "dw_stream_fwd", **TOL[dt])
+    close(ssum, ref.sum(1), "dw_stream_ssum", rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * T ** 0.5)
+    close(ssq, (ref ** 2).sum(1), "dw_stream_ssq", rtol=TOL[dt]["rtol"], atol=TOL[dt]["atol"] * T)
+    # the tile kernel on the same inputs: the same fp32 sum per output element (taps in the same order, bias last) -> the same bf16 outputs up to
+    # an occasional last-bit difference where the compiler contracted a multiply-add in one kernel only
+    y2 = torch.empty_like(y)
+    lib.ishara_debug_force_regstage(4)
+    try:
+        _lib.check(lib.ishara_op_dwconv_fwd_ex(code, inop, _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y2), _lib.ptr(ssum), _lib.ptr(ssq), scp, B, T, Cc, k, padl, stream()))
+    finally:
+        lib.ishara_debug_force_regstage(0)
+    torch.cuda.synchronize()
+    ndiff = int((y != y2).sum().item())
+    assert ndiff <= 1e-3 * y.numel() and (y.float() - y2.float()).abs().max().item() <= 2 ** -6 * max(1.0, y2.float().abs().max().item()), (ndiff, y.numel())
+
+
 def _attn_ref(qkv, B, H, T, dh, scale, mask):
     d = H * dh
     q4 = qkv.view(B, T, H, 3 * dh).permute(0, 2, 1, 3)
