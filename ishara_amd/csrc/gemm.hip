@@ -945,7 +945,7 @@ static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int 
 
 // name of the kernel launch_gemm_nt / launch_gemm_tn will pick (profiler keys = rocprof kernel names)
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
-const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea);
+const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea, int M, int N);
 const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb);
 int g_force_regstage = 0;   // NT kernel choice: 0 A-stationary kernel (gemm_as.hip) where it applies, else the 128x128 LDS-DMA tile kernel; 3 tile kernel only; 2 LDS-DMA 64x128 kernel; 1 register-staged
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
@@ -2120,7 +2120,7 @@ const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A
     if (dtM == DT_F16) return "gemm_nt_kernel<f16>";
     const int bk = dtM == DT_BF16 ? 32 : 16;
     const bool dma = op == OP_NONE && dtA == dtM && K % bk == 0 && ldb % (2 * bk) == 0 && ((uintptr_t)A) % 16 == 0;
-    if (dma && g_force_regstage == 0 && dtM == DT_BF16 && gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return gemm_nt_as_name(dtC, K, ea);
+    if (dma && g_force_regstage == 0 && dtM == DT_BF16 && gemm_nt_as_applicable(dtC, M, N, K, ldb, ea)) return gemm_nt_as_name(dtC, K, ea, M, N);
     if (dma && (g_force_regstage == 0 || g_force_regstage == 3)) return dtM == DT_F32 ? "gemm_nt_t_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_t_kernel<bf16,f32>" : "gemm_nt_t_kernel<bf16,bf16>");
     if (dma && g_force_regstage != 1) return dtM == DT_F32 ? "gemm_nt_glds_kernel<f32,f32>" : (dtC == DT_F32 ? "gemm_nt_glds_kernel<bf16,f32>" : "gemm_nt_glds_kernel<bf16,bf16>");
     if (dtA == DT_F32 && dtM == DT_BF16) return "gemm_nt_kernel<f32,bf16,bf16>";

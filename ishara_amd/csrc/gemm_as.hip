@@ -107,15 +107,19 @@ template <int MASK, int F> DEVI bool as_on(bool runtime) {
 // RT row tiles of 16.  KT = K / 32 (8 or 16); MASK: epilogue features.
 // PRO: operand prologue — 0 none, 1 LayerNorm over K (ea.ln_*), 2 per-sample affine (ea.pa_*); both write the transformed rows to
 // ea.pro_out when it is set.  The coefficient vectors are staged in the ring slot the DMA fills last (free until step 0's issue).
-template <typename TC, int KT, int MASK, int RT, int DBG, int PRO, int NW = 4>
+// CS > 1: the CHUNKED form — a stage holds CS column steps (CS * 32 weight rows), two stages; the DMA wait, the barrier and the next stage's DMA
+// issue happen once per CS steps, the steps inside a stage run without any synchronisation (see gemm_nt_as_chunk_kernel).
+template <typename TC, int KT, int MASK, int RT, int DBG, int PRO, int NW = 4, int CS = 1>
 DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, const EpiArgs& ea,
                   char* smem, const float* bias_s, int m_base) {
     constexpr int RB = KT * 64;                    // bytes of one staged weight row (full K)
     constexpr int NS = AS_NS;                      // output columns per step
-    constexpr int STAGE = NS * RB;                 // 16 KB (K=256) / 32 KB (K=512)
-    constexpr int R = KT <= 8 ? 3 : 2;             // ring depth: 48 KB / 64 KB of LDS
+    constexpr int SUB = NS * RB;                   // bytes of one column step's weight rows: 16 KB (K=256) / 32 KB (K=512)
+    constexpr int STAGE = SUB * CS;                // one DMA stage
+    constexpr int R = CS > 1 ? 2 : (KT <= 8 ? 3 : 2);      // ring depth: 48 KB / 64 KB of LDS (chunked: 2 x 64 KB at K = 256, CS = 4)
     constexpr int K = KT * 32;
-    constexpr int DPW = STAGE / 1024 / NW;         // 1 KB DMA instructions per wave per stage (NW waves per workgroup)
+    constexpr int NI = STAGE / 1024;               // 1 KB DMA instructions per stage
+    constexpr int DPW = (NI + NW - 1) / NW;        // ... per wave (NW waves per workgroup); when NW does not divide NI the last waves repeat the first pieces
     constexpr bool PAIR = is_16b_t<TC>::value;     // pair MFMA tiles so that a lane owns 8 consecutive columns (16-byte bf16 accesses)
     constexpr int GW = PAIR ? 8 : 4;               // columns per lane per group
     constexpr int NG = NS / (4 * GW);              // groups per row tile per step: 1 (bf16 C) / 2 (f32 C)
@@ -150,22 +154,23 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
     const as_t* bsrc[DPW];
 #pragma unroll
     for (int t = 0; t < DPW; ++t) {
-        const int o = (wid * DPW + t) * 1024 + lane * 16;
+        const int o = ((wid * DPW + t) % NI) * 1024 + lane * 16;
         const int r = o / RB, p = (o % RB) >> 4;
         bsrc[t] = Bt + (size_t)(nbase + r) * ldb + ((p ^ as_swz(r)) << 3);
     }
-    const size_t bstep = (size_t)NS * ldb;
+    const size_t bstep = (size_t)NS * CS * ldb;
     auto issue = [&](int slot) {
 #pragma unroll
         for (int t = 0; t < DPW; ++t) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc[t],
-                                             (__attribute__((address_space(3))) void*)(smem + slot + (wid * DPW + t) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + slot + ((wid * DPW + t) % NI) * 1024), 16, 0, 0);
             bsrc[t] += bstep;
         }
     };
+    const int nstages = (nsteps + CS - 1) / CS;
 #pragma unroll
     for (int st = 0; st < R - 1; ++st)
-        if (st < nsteps && !(dbg & 8)) issue(st * STAGE);       // dbg: ablation bits of tools/gemm_ablate.py (1 no epilogue, 2 no MFMA, 4 no LDS reads, 8 no DMA)
+        if (st < nstages && !(dbg & 8)) issue(st * STAGE);       // dbg: ablation bits of tools/gemm_ablate.py (1 no epilogue, 2 no MFMA, 4 no LDS reads, 8 no DMA)
 
     // A fragments: lane (c, g) holds row 16i + c, k = 32kt + 8g .. +7
     as_v8 a[RT][KT];
@@ -298,19 +303,27 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
         // ---- T1: stage s has landed.  Younger operations that may stay in flight (in-order VM counter): the DMAs of
         // stages s+1 .. s+R-2 and, when the epilogue is a fixed number of stores and the row block is full, the stores
         // of the R-1 steps since its issue.
-        if constexpr (COUNTED) {
-            if (full && !ea.n_valid && s >= R - 1 && s + R - 2 < nsteps) {
-                if (!hold) as_wait_vm<(R - 2) * DPW + (R - 1) * OPS>();
-                // held stores leave in pairs at the odd steps: of the two steps since stage s was requested exactly one was odd (R = 3);
-                // with R = 2 only the step before this one counts — a pair when it was odd, nothing when it was even
-                else if constexpr (R == 3) as_wait_vm<DPW + 2 * OPS>();
-                else { if (s & 1) as_wait_vm<0>(); else as_wait_vm<2 * OPS>(); }
-            } else as_wait_vm<0>();
-        } else {
-            if (s + R - 2 < nsteps) as_wait_vm<(R - 2) * DPW>(); else as_wait_vm<0>();
+        const int sub = CS > 1 ? (s & (CS - 1)) : 0;          // column step inside the stage (CS is a power of two)
+        const bool sync = CS == 1 || sub == 0;                // chunked: wait / barrier / next DMA once per stage
+        const int sg = CS > 1 ? s / CS : s;                   // stage index
+        if (sync) {
+            if constexpr (CS > 1) {
+                // two stages: stage sg's DMA was issued at the previous stage boundary, in front of that stage's CS steps of stores
+                if (COUNTED && full && !ea.n_valid && sg >= 1) as_wait_vm<CS * OPS>(); else as_wait_vm<0>();
+            } else if constexpr (COUNTED) {
+                if (full && !ea.n_valid && s >= R - 1 && s + R - 2 < nsteps) {
+                    if (!hold) as_wait_vm<(R - 2) * DPW + (R - 1) * OPS>();
+                    // held stores leave in pairs at the odd steps: of the two steps since stage s was requested exactly one was odd (R = 3);
+                    // with R = 2 only the step before this one counts — a pair when it was odd, nothing when it was even
+                    else if constexpr (R == 3) as_wait_vm<DPW + 2 * OPS>();
+                    else { if (s & 1) as_wait_vm<0>(); else as_wait_vm<2 * OPS>(); }
+                } else as_wait_vm<0>();
+            } else {
+                if (s + R - 2 < nsteps) as_wait_vm<(R - 2) * DPW>(); else as_wait_vm<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
         const int n0 = nbase + s * NS;
         // ---- T3: residual / act' operand loads of this step (consumed after the MFMA phase), then DMA of stage s+R-1
         // into the slot read in step s-1
@@ -327,14 +340,14 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
 #pragma unroll
                 for (int q = 0; q < NG; ++q) au[i][q] = __builtin_nontemporal_load(reinterpret_cast<const as_u32x4*>(aux + eoff[i] + n0 + 4 * GW * q));      // last use of a saved pre-activation
         }
-        if (s + R - 1 < nsteps && !(dbg & 8)) issue(slot == 0 ? (R - 1) * STAGE : slot - STAGE);
+        if (sync && sg + R - 1 < nstages && !(dbg & 8)) issue(slot == 0 ? (R - 1) * STAGE : slot - STAGE);
         // ---- MFMA: acc[j][i] = sum_k Bt[row(j), k] * A[16i + .., k]
         f32x4 acc[2][RT];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* st = smem + slot;
+        const char* st = smem + slot + sub * SUB;
         if (!(dbg & 6)) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
@@ -365,7 +378,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[0][i][0] = (float)a[i][0][0] + (float)a[i][KT - 1][7];
         }
-        if (dbg & 1) { if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][RT - 1][2]); slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE; continue; }
+        if (dbg & 1) { if (acc[0][0][0] == 123.456f) C[0] = from_f<TC>(acc[1][RT - 1][2]); if (CS == 1 || sub == CS - 1) slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE; continue; }
         // ---- epilogue from the accumulators: lane owns row 16i + c and, per group q, columns n0 + 4*GW*q + GW*g .. +GW-1
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -475,7 +488,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
                 }
             }
         }
-        slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE;
+        if (CS == 1 || sub == CS - 1) slot = slot == (R - 1) * STAGE ? 0 : slot + STAGE;
     }
     // the prologue's transformed rows, for the backward pass: stored AFTER the column loop (the fragments are still in registers), so
     // that these stores do not sit in front of the loop's counted vmcnt waits and drain beside other workgroups' loops
@@ -528,6 +541,34 @@ __global__ __launch_bounds__(KT <= 16 ? 256 : 512, KT <= 8 ? 3 : (KT <= 16 ? 2 :
     }
 }
 
+// CHUNKED form for K = 256 at large M (bf16 training shapes): ONE workgroup of 12 waves per CU owns 384 rows (256 workgroups at M = 98304);
+// the weight matrix streams through two 64 KB stages of 128 output columns each, so the DMA wait + workgroup barrier + next DMA issue happen
+// once per FOUR column steps (4 / 6 per GEMM instead of 16 / 24) and a stage's DMA is requested a whole stage (four steps of MFMA + stores)
+// ahead.  Why: every memory instruction of a CU goes through one in-order queue; when the store stream backs it up (the kernel is
+// HBM-write bound), the per-step weight DMA of the 16 KB ring arrives late and its wait + barrier stall all four waves of a workgroup every
+// step — phase ablation on cold operands (tools/gemm_cold_ablate.py): loads + stores alone 31.6 us, + DMA / LDS / MFMA 40.7 us, i.e. the
+// compute side does not hide under the store stream.  With the wait amortised over four steps the waves drift apart and compute overlaps stores.
+#define AS_CHUNK_CS 4
+#define AS_CHUNK_NW 12
+#define AS_CHUNK_ROWS (AS_CHUNK_NW * 32)
+template <typename TC, int KT, int MASK, int PRO = 0>
+__global__ __launch_bounds__(AS_CHUNK_NW * 64, 1) void gemm_nt_as_chunk_kernel(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, EpiArgs ea) {
+    extern __shared__ __attribute__((aligned(16))) char csm[];
+    constexpr int STAGE = AS_NS * KT * 64 * AS_CHUNK_CS;
+    float* bias_s = reinterpret_cast<float*>(csm + 2 * STAGE);
+    for (int n = threadIdx.x; n < N; n += (int)blockDim.x) bias_s[n] = (ea.bias && (!ea.n_valid || n < ea.n_valid)) ? ea.bias[n] : 0.f;
+    as_pass<TC, KT, MASK, 2, 0, PRO, AS_CHUNK_NW, AS_CHUNK_CS>(A, Bt, C, M, N, ldb, ea, csm, bias_s, blockIdx.x * AS_CHUNK_ROWS);
+}
+template <typename KF> static bool as_chunk_prepare(KF kernel, int bytes) {      // dynamic LDS above 64 KB needs the attribute once per kernel
+    static std::map<const void*, bool> done;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    auto it = done.find(key);
+    if (it != done.end()) return it->second;
+    const bool ok = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    done[key] = ok;
+    return ok;
+}
+
 static int as_mask_of(const EpiArgs& ea) {
     return (ea.resid ? AS_RESID : 0) | (ea.dact != DACT_NONE ? AS_DACT : 0) | (ea.act != ACT_NONE ? AS_ACT : 0) | (ea.drop.thr ? AS_DROP : 0) |
            (ea.rowscale ? AS_ROWSCALE : 0) | (ea.pre_out ? AS_PREOUT : 0) | (ea.mode == EPI_QKV ? AS_QKV : 0) | (ea.addtab ? AS_ADDTAB : 0);
@@ -544,11 +585,32 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
     }
 }
 
-#define AS_LAUNCH(MASK) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
+#define AS_LAUNCH_PLAIN(MASK, PRO) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK, 0, PRO>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
+#ifdef AS_F16
+#define AS_LAUNCH2(MASK, PRO) AS_LAUNCH_PLAIN(MASK, PRO)
+#else
+// K = 256, bf16 C, large M, whole stages: the chunked kernel (as_flags bit 4)
+#define AS_LAUNCH2(MASK, PRO)                                                                                                         \
+    do {                                                                                                                              \
+        if constexpr (KT == 8 && std::is_same<TC, as_t>::value && (MASK) != AS_ALL) {                                                 \
+            constexpr int CB = 2 * AS_NS * KT * 64 * AS_CHUNK_CS + AS_MAXN * 4;                                                       \
+            if (chunked && as_chunk_prepare(gemm_nt_as_chunk_kernel<TC, KT, MASK, PRO>, CB)) {                                        \
+                hipLaunchKernelGGL((gemm_nt_as_chunk_kernel<TC, KT, MASK, PRO>), dim3((M + AS_CHUNK_ROWS - 1) / AS_CHUNK_ROWS), dim3(AS_CHUNK_NW * 64), CB, s, \
+                                   (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea);                                           \
+                break;                                                                                                                \
+            }                                                                                                                         \
+        }                                                                                                                             \
+        AS_LAUNCH_PLAIN(MASK, PRO);                                                                                                   \
+    } while (0)
+#endif
+#define AS_LAUNCH(MASK) AS_LAUNCH2(MASK, 0)
 // library default of EpiArgs.as_flags (bit 0 paired half-line stores, bit 1 non-temporal side outputs); ISHARA_AS_FLAGS overrides (A/B runs)
 static int as_default_flags() {
-    static const int v = getenv("ISHARA_AS_FLAGS") ? atoi(getenv("ISHARA_AS_FLAGS")) : 3;
+    static const int v = getenv("ISHARA_AS_FLAGS") ? atoi(getenv("ISHARA_AS_FLAGS")) : 3;      // + 16: the chunked K = 256 kernel
     return v;
+}
+static bool as_chunk_applies(int flags, int M, int N, const EpiArgs& ea) {      // (K = 256, bf16 C checked by the caller)
+    return (flags & 16) && M >= 128 * AS_CHUNK_ROWS && (N / AS_NS) % AS_CHUNK_CS == 0 && N >= 128 && !ea.n_valid && !ea.dbg && (!ea.pa_P || (ea.T > 0 && ea.T % AS_CHUNK_ROWS == 0));
 }
 template <typename TC, int KT>
 static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea_in, hipStream_t s) {
@@ -564,8 +626,11 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     while (gy < max_gy && gx * gy * 2 <= slots && (N / AS_NS) % (gy * 2) == 0 && N / (gy * 2) >= min_cols) gy *= 2;
     const dim3 grid(gx, gy), block(KT <= 16 ? 256 : 512);
     const int mask = as_mask_of(ea);
+    // chunked form (K = 256): whole 128-column stages, rows enough to give every CU a 384-row workgroup, no column split, no narrow output
+    const bool chunked = KT == 8 && as_chunk_applies(ea.as_flags, M, N, ea) && gy == 1;
+    (void)chunked;
     if constexpr (is_16b_t<TC>::value && KT >= 8) {
-#define AS_PRO(MASK, PRO) hipLaunchKernelGGL((gemm_nt_as_kernel<TC, KT, MASK, 0, PRO>), grid, block, 0, s, (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea)
+#define AS_PRO(MASK, PRO) AS_LAUNCH2(MASK, PRO)
         if (ea.ln_gamma) {           // LayerNorm prologue: the GEMMs that consume a LayerNorm output (FFN expand, QKV, conv-module expand)
             switch (mask) {
                 case 0: AS_PRO(0, 1); break;
@@ -653,15 +718,17 @@ bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs&
 }
 
 // profiler key = the rocprof kernel name of the instantiation launch_gemm_nt_as runs
-const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea) {
+const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea, int M, int N) {
     static std::map<int, std::string> names;
     const int inst = as_inst_mask(dtC == DT_BF16, as_mask_of(ea), K);
     const int pro = ea.ln_gamma ? 1 : (ea.pa_P ? 2 : 0);
-    const int id = (dtC == DT_BF16 ? 0 : 1 << 20) | (pro << 22) | (K << 8) | inst;
+    const bool chunk = dtC == DT_BF16 && K == 256 && inst != AS_ALL && as_chunk_applies(ea.as_flags < 0 ? as_default_flags() : ea.as_flags, M, N, ea);
+    const int id = (dtC == DT_BF16 ? 0 : 1 << 20) | (pro << 22) | (chunk ? 1 << 24 : 0) | (K << 8) | inst;
     auto it = names.find(id);
     if (it == names.end()) {
         char buf[96];
-        if (pro) snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d,0,%d>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, as_mask_of(ea), pro);
+        if (chunk) snprintf(buf, sizeof buf, "gemm_nt_as_chunk_kernel<bf16,%d,%d,%d>", K / 32, pro ? as_mask_of(ea) : inst, pro);
+        else if (pro) snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d,0,%d>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, as_mask_of(ea), pro);
         else snprintf(buf, sizeof buf, "gemm_nt_as_kernel<%s,%d,%d,0>", dtC == DT_BF16 ? "bf16" : "f32", K / 32, inst);
         it = names.emplace(id, buf).first;
     }
