@@ -155,6 +155,8 @@ int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, int32_t cols
 
 /* tests/ablation: bit0 register-staged NT GEMM, bit1 register-transposing TN GEMM, bit2 LDS-tiled depthwise conv
  * (defaults: LDS-DMA NT, transposed-read TN, register-window depthwise conv); bits 4-11 ablation switches */
+/* switches of the A-stationary GEMM (1 paired half-line stores, 2 non-temporal side outputs, 16 chunked K = 256 form); -1 = library default */
+int ishara_debug_set_as_flags(int32_t flags);
 int ishara_debug_force_regstage(int32_t on);
 
 /* ---- single-operator entry points (parity tests of the individual kernels) ------------ */

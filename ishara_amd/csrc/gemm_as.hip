@@ -605,9 +605,14 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
 #endif
 #define AS_LAUNCH(MASK) AS_LAUNCH2(MASK, 0)
 // library default of EpiArgs.as_flags (bit 0 paired half-line stores, bit 1 non-temporal side outputs); ISHARA_AS_FLAGS overrides (A/B runs)
+#ifdef AS_F16
+extern int g_as_flags_override;
+#else
+int g_as_flags_override = -1;       // tests / A-B runs inside one process (ishara_debug_set_as_flags)
+#endif
 static int as_default_flags() {
     static const int v = getenv("ISHARA_AS_FLAGS") ? atoi(getenv("ISHARA_AS_FLAGS")) : 3;      // + 16: the chunked K = 256 kernel
-    return v;
+    return g_as_flags_override >= 0 ? g_as_flags_override : v;
 }
 static bool as_chunk_applies(int flags, int M, int N, const EpiArgs& ea) {      // (K = 256, bf16 C checked by the caller)
     return (flags & 16) && M >= 128 * AS_CHUNK_ROWS && (N / AS_NS) % AS_CHUNK_CS == 0 && N >= 128 && !ea.n_valid && !ea.dbg && (!ea.pa_P || (ea.T > 0 && ea.T % AS_CHUNK_ROWS == 0));

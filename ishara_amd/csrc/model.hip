@@ -1041,6 +1041,9 @@ extern "C" int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, i
 extern int g_force_regstage, g_dbg_tn, g_force_tn_regstage, g_force_dw_lds, g_tn_blocks, g_attn_bwd_two_pass;
 static int g_dbg_epi = 0;
 // bit 0: 1 register-staged NT kernel / 0 LDS-DMA NT kernel; bit 1: 1 register-transposing TN kernel; bit 2: 1 LDS-tiled dwconv; bit 3: 1 LDS-DMA 64x128 NT kernel; bits 4-7: NT ablation; bits 8-12: TN ablation; bit 13: 1 tile NT kernel instead of the A-stationary one; bits 14-15: wgrad workgroups auto / 256 / 512 / 768; bit 16: 1 two-kernel attention backward instead of the one-pass kernel
+extern int g_as_flags_override;
+// A-stationary GEMM switches (gemm_as.hip as_default_flags: 1 paired half-line stores, 2 non-temporal side outputs, 16 chunked K = 256 form); -1: library default
+extern "C" int ishara_debug_set_as_flags(int32_t flags) { g_as_flags_override = flags; return 0; }
 extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = (on & 1) ? 1 : ((on >> 3) & 1 ? 2 : ((on >> 13) & 1 ? 3 : 0)); g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 31; g_force_tn_regstage = (on >> 1) & 1; g_force_dw_lds = (on >> 2) & 1; { const int tb = (on >> 14) & 3; g_tn_blocks = tb == 1 ? 256 : (tb == 2 ? 512 : (tb == 3 ? 768 : 0)); } g_attn_bwd_two_pass = (on >> 16) & 1; return 0; }
 
 extern "C" int ishara_preprocess(const float* raw, const int32_t* n_frames, int32_t max_frames, const float* mean, const float* stdv,
