@@ -309,7 +309,10 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
         if (sync) {
             if constexpr (CS > 1) {
                 // two stages: stage sg's DMA was issued at the previous stage boundary, in front of that stage's CS steps of stores
-                if (COUNTED && full && !ea.n_valid && sg >= 1) as_wait_vm<CS * OPS>(); else as_wait_vm<0>();
+                // (also with residual / act' operand loads in the epilogue: they were consumed, hence complete, before the stage boundary, so the only
+                // operations younger than the DMA that can still be pending are the CS steps' stores)
+                constexpr bool CCOUNT = MASK != AS_ALL && (MASK & AS_QKV) == 0;
+                if (CCOUNT && full && !ea.n_valid && sg >= 1) as_wait_vm<CS * OPS>(); else as_wait_vm<0>();
             } else if constexpr (COUNTED) {
                 if (full && !ea.n_valid && s >= R - 1 && s + R - 2 < nsteps) {
                     if (!hold) as_wait_vm<(R - 2) * DPW + (R - 1) * OPS>();
@@ -548,16 +551,27 @@ __global__ __launch_bounds__(KT <= 16 ? 256 : 512, KT <= 8 ? 3 : (KT <= 16 ? 2 :
 // HBM-write bound), the per-step weight DMA of the 16 KB ring arrives late and its wait + barrier stall all four waves of a workgroup every
 // step — phase ablation on cold operands (tools/gemm_cold_ablate.py): loads + stores alone 31.6 us, + DMA / LDS / MFMA 40.7 us, i.e. the
 // compute side does not hide under the store stream.  With the wait amortised over four steps the waves drift apart and compute overlaps stores.
-#define AS_CHUNK_CS 4
-#define AS_CHUNK_NW 12
-#define AS_CHUNK_ROWS (AS_CHUNK_NW * 32)
+// K = 512: the A fragments take 128 registers, 8 waves per CU: stages of 64 columns (2 steps), a 256-row pass (32 rows per wave) followed by a
+// 128-row pass (16 rows per wave) over the same 384 rows-per-workgroup split.
+#define AS_CHUNK_ROWS 384
+template <int KT> struct AsChunk { static constexpr int NW = KT <= 8 ? 12 : 8, CS = KT <= 8 ? 4 : 2; };
 template <typename TC, int KT, int MASK, int PRO = 0>
-__global__ __launch_bounds__(AS_CHUNK_NW * 64, 1) void gemm_nt_as_chunk_kernel(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, EpiArgs ea) {
+__global__ __launch_bounds__(AsChunk<KT>::NW * 64, 1) void gemm_nt_as_chunk_kernel(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* __restrict__ C, int M, int N, int ldb, EpiArgs ea) {
     extern __shared__ __attribute__((aligned(16))) char csm[];
-    constexpr int STAGE = AS_NS * KT * 64 * AS_CHUNK_CS;
+    constexpr int NW = AsChunk<KT>::NW, CS = AsChunk<KT>::CS;
+    constexpr int STAGE = AS_NS * KT * 64 * CS;
     float* bias_s = reinterpret_cast<float*>(csm + 2 * STAGE);
     for (int n = threadIdx.x; n < N; n += (int)blockDim.x) bias_s[n] = (ea.bias && (!ea.n_valid || n < ea.n_valid)) ? ea.bias[n] : 0.f;
-    as_pass<TC, KT, MASK, 2, 0, PRO, AS_CHUNK_NW, AS_CHUNK_CS>(A, Bt, C, M, N, ldb, ea, csm, bias_s, blockIdx.x * AS_CHUNK_ROWS);
+    const int m_base = blockIdx.x * AS_CHUNK_ROWS;
+    if constexpr (KT <= 8) {
+        as_pass<TC, KT, MASK, 2, 0, PRO, NW, CS>(A, Bt, C, M, N, ldb, ea, csm, bias_s, m_base);
+    } else {
+        as_pass<TC, KT, MASK, 2, 0, PRO, NW, CS>(A, Bt, C, M, N, ldb, ea, csm, bias_s, m_base);
+        if (m_base + 256 < M) {
+            __builtin_amdgcn_s_barrier();          // every wave is done reading the stages before the second pass refills them
+            as_pass<TC, KT, MASK, 1, 0, PRO, NW, CS>(A, Bt, C, M, N, ldb, ea, csm, bias_s, m_base + 256);
+        }
+    }
 }
 template <typename KF> static bool as_chunk_prepare(KF kernel, int bytes) {      // dynamic LDS above 64 KB needs the attribute once per kernel
     static std::map<const void*, bool> done;
@@ -592,10 +606,10 @@ static int as_inst_mask(bool c_bf16, int mask, int K = 256) {
 // K = 256, bf16 C, large M, whole stages: the chunked kernel (as_flags bit 4)
 #define AS_LAUNCH2(MASK, PRO)                                                                                                         \
     do {                                                                                                                              \
-        if constexpr (KT == 8 && std::is_same<TC, as_t>::value && (MASK) != AS_ALL) {                                                 \
-            constexpr int CB = 2 * AS_NS * KT * 64 * AS_CHUNK_CS + AS_MAXN * 4;                                                       \
+        if constexpr ((KT == 8 || KT == 16) && std::is_same<TC, as_t>::value && (MASK) != AS_ALL) {                                   \
+            constexpr int CB = 2 * AS_NS * KT * 64 * AsChunk<KT>::CS + AS_MAXN * 4;                                                   \
             if (chunked && as_chunk_prepare(gemm_nt_as_chunk_kernel<TC, KT, MASK, PRO>, CB)) {                                        \
-                hipLaunchKernelGGL((gemm_nt_as_chunk_kernel<TC, KT, MASK, PRO>), dim3((M + AS_CHUNK_ROWS - 1) / AS_CHUNK_ROWS), dim3(AS_CHUNK_NW * 64), CB, s, \
+                hipLaunchKernelGGL((gemm_nt_as_chunk_kernel<TC, KT, MASK, PRO>), dim3((M + AS_CHUNK_ROWS - 1) / AS_CHUNK_ROWS), dim3(AsChunk<KT>::NW * 64), CB, s, \
                                    (const as_t*)A, (const as_t*)Bt, (TC*)C, M, N, ldb, ea);                                           \
                 break;                                                                                                                \
             }                                                                                                                         \
@@ -614,8 +628,11 @@ static int as_default_flags() {
     static const int v = getenv("ISHARA_AS_FLAGS") ? atoi(getenv("ISHARA_AS_FLAGS")) : 3;      // + 16: the chunked K = 256 kernel
     return g_as_flags_override >= 0 ? g_as_flags_override : v;
 }
-static bool as_chunk_applies(int flags, int M, int N, const EpiArgs& ea) {      // (K = 256, bf16 C checked by the caller)
-    return (flags & 16) && M >= 128 * AS_CHUNK_ROWS && (N / AS_NS) % AS_CHUNK_CS == 0 && N >= 128 && !ea.n_valid && !ea.dbg && (!ea.pa_P || (ea.T > 0 && ea.T % AS_CHUNK_ROWS == 0));
+static bool as_chunk_applies(int flags, int M, int N, int K, const EpiArgs& ea) {      // (bf16 C checked by the caller); bit 4: K = 256, bit 5: K = 512
+    const int cs = K == 256 ? 4 : 2;
+    // PSA prologue: a workgroup's rows (both passes at K = 512: 256 + 128) must lie inside one sample
+    return (K == 256 ? (flags & 16) : (K == 512 && (flags & 32))) && M >= 128 * AS_CHUNK_ROWS && (N / AS_NS) % cs == 0 && N >= 128 && !ea.n_valid && !ea.dbg &&
+           (!ea.pa_P || (ea.T > 0 && ea.T % AS_CHUNK_ROWS == 0));
 }
 template <typename TC, int KT>
 static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb, const EpiArgs& ea_in, hipStream_t s) {
@@ -632,7 +649,7 @@ static int run_as(const void* A, const void* Bt, void* C, int M, int N, int ldb,
     const dim3 grid(gx, gy), block(KT <= 16 ? 256 : 512);
     const int mask = as_mask_of(ea);
     // chunked form (K = 256): whole 128-column stages, rows enough to give every CU a 384-row workgroup, no column split, no narrow output
-    const bool chunked = KT == 8 && as_chunk_applies(ea.as_flags, M, N, ea) && gy == 1;
+    const bool chunked = (KT == 8 || KT == 16) && as_chunk_applies(ea.as_flags, M, N, KT * 32, ea) && gy == 1;
     (void)chunked;
     if constexpr (is_16b_t<TC>::value && KT >= 8) {
 #define AS_PRO(MASK, PRO) AS_LAUNCH2(MASK, PRO)
@@ -727,7 +744,7 @@ const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea, int M, int N) {
     static std::map<int, std::string> names;
     const int inst = as_inst_mask(dtC == DT_BF16, as_mask_of(ea), K);
     const int pro = ea.ln_gamma ? 1 : (ea.pa_P ? 2 : 0);
-    const bool chunk = dtC == DT_BF16 && K == 256 && inst != AS_ALL && as_chunk_applies(ea.as_flags < 0 ? as_default_flags() : ea.as_flags, M, N, ea);
+    const bool chunk = dtC == DT_BF16 && inst != AS_ALL && as_chunk_applies(ea.as_flags < 0 ? as_default_flags() : ea.as_flags, M, N, K, ea);
     const int id = (dtC == DT_BF16 ? 0 : 1 << 20) | (pro << 22) | (chunk ? 1 << 24 : 0) | (K << 8) | inst;
     auto it = names.find(id);
     if (it == names.end()) {

@@ -103,15 +103,16 @@ def test_dense_fwd_residual(lib, dt, M, K, N, act, regstage):
     close(y, ref, "dense_fwd_residual", **TOL[dt])
 
 
-@pytest.mark.parametrize("M,N,act,with_resid", [(49152, 512, 0, False), (49152 + 200, 256, 1, False), (49152, 768, 0, True), (50000, 512, 2, True)])
-def test_dense_chunked_a_stationary_kernel(lib, M, N, act, with_resid):
+@pytest.mark.parametrize("M,K,N,act,with_resid", [(49152, 256, 512, 0, False), (49152 + 200, 256, 256, 1, False), (49152, 256, 768, 0, True), (50000, 256, 512, 2, True),
+                                                  (49152, 512, 256, 0, True), (49152 + 300, 512, 256, 1, False), (49152 + 130, 512, 512, 0, True)])
+def test_dense_chunked_a_stationary_kernel(lib, M, K, N, act, with_resid):
     """The chunked form of the A-stationary GEMM (gemm_as.hip gemm_nt_as_chunk_kernel: K = 256, M >= 49152 rows, one 12-wave workgroup of
-    384 rows per CU, two 64 KB weight stages of 128 columns) — reached only at training-size M, so it gets its own case: against the fp64
+    384 rows per CU, two 64 KB weight stages of 128 columns; K = 512: 8 waves, stages of 64 columns, a 256-row and a 128-row pass) — reached
+    only at training-size M, so it gets its own case: against the fp64
     reference on sampled rows (the whole product would be 13 GFLOP of CPU fp64) and BIT-IDENTICAL to the per-step kernel on every element
     (same fragments, same MFMA order, same epilogue arithmetic).  Ragged M (a partial last workgroup), all three stage counts (N = 256 / 512 /
     768), bias + activation + residual epilogues."""
     code, tdt = DT["bf16"]
-    K = 256
     g = torch.Generator().manual_seed(M + N + act)
     x = torch.randn(M, K, generator=g).to(tdt)
     W = torch.randn(K, N, generator=g) / K ** 0.5
@@ -123,7 +124,7 @@ def test_dense_chunked_a_stationary_kernel(lib, M, N, act, with_resid):
     scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
     outs = {}
     try:
-        for flags in (3, 19):
+        for flags in (3, 51):
             lib.ishara_debug_set_as_flags(flags)
             y = torch.empty(M, N, dtype=tdt, device="cuda")
             _lib.check(lib.ishara_op_dense_fwd_ex(code, _lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), M, K, N, act, scp, stream()))
@@ -131,13 +132,13 @@ def test_dense_chunked_a_stationary_kernel(lib, M, N, act, with_resid):
             outs[flags] = y
     finally:
         lib.ishara_debug_set_as_flags(-1)
-    assert torch.equal(outs[3], outs[19]), f"chunked vs per-step kernel: {(outs[3].float() - outs[19].float()).abs().max().item()}"
+    assert torch.equal(outs[3], outs[51]), f"chunked vs per-step kernel: {(outs[3].float() - outs[51].float()).abs().max().item()}"
     rows = torch.cat([torch.arange(0, 700), torch.arange(M // 2 - 200, M // 2 + 200), torch.arange(M - 500, M)])
     ref = x[rows].double() @ W.to(tdt).double() + b.double()
     ref = [ref, ref * torch.sigmoid(ref), torch.relu(ref)][act]
     if with_resid:
         ref = ref + r[rows].double()
-    close(outs[19][rows.cuda()], ref, "dense_chunked", **TOL["bf16"])
+    close(outs[51][rows.cuda()], ref, "dense_chunked", **TOL["bf16"])
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
