@@ -625,7 +625,7 @@ extern int g_as_flags_override;
 int g_as_flags_override = -1;       // tests / A-B runs inside one process (ishara_debug_set_as_flags)
 #endif
 static int as_default_flags() {
-    static const int v = getenv("ISHARA_AS_FLAGS") ? atoi(getenv("ISHARA_AS_FLAGS")) : 3;      // + 16: the chunked K = 256 kernel
+    static const int v = getenv("ISHARA_AS_FLAGS") ? atoi(getenv("ISHARA_AS_FLAGS")) : 51;     // 1 paired stores | 2 nt side outputs | 16 chunked K = 256 | 32 chunked K = 512
     return g_as_flags_override >= 0 ? g_as_flags_override : v;
 }
 static bool as_chunk_applies(int flags, int M, int N, int K, const EpiArgs& ea) {      // (bf16 C checked by the caller); bit 4: K = 256, bit 5: K = 512

@@ -54,7 +54,8 @@ struct EpiArgs {
     int ldc = 0, n_valid = 0;
     // A-stationary kernel, 16-bit C: bit 0 — a row's two 64-byte halves of a 128-byte line are stored back to back every second column step
     // instead of one step apart (cold HBM takes half lines that arrive a step apart at 3.8 TB/s, whole lines at 4.6+: tools/micro/store_cold.hip);
-    // bit 1 — non-temporal hint on the side outputs (saved pre-activations, prologue rows).  -1: the library default (gemm_as.hip, ISHARA_AS_FLAGS)
+    // bit 1 — non-temporal hint on the side outputs (saved pre-activations, prologue rows); bits 4 / 5 — the chunked form (one workgroup per CU, 64 KB
+    // weight stages, a wait + barrier per stage instead of per column step) at K = 256 / 512.  -1: the library default (gemm_as.hip, ISHARA_AS_FLAGS)
     int as_flags = -1;
 };
 
