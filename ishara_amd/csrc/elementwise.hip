@@ -1277,13 +1277,14 @@ DEVI double fin_fold(double v) {
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nb, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ mmean, float* __restrict__ mvar, int training,
-                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ bsh, int C, float var_corr) {
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ bsh, int C, float var_corr, int stride) {
+    // stride: floats between consecutive rows of ssum / ssq (C: [nb, C] arrays; 2C: the depthwise conv's partial statistic rows [nb][2][C] read in place)
     __shared__ double rs_[FIN_NW][FIN_CL], rq_[FIN_NW][FIN_CL];
     const int cl = threadIdx.x & (FIN_CL - 1), bl = threadIdx.x / FIN_CL, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * FIN_CL + cl;
     double s = 0.0, q = 0.0;
     if (training && c < C)
-        for (int b = bl; b < nb; b += FIN_BL) { s += (double)ssum[(size_t)b * C + c]; q += (double)ssq[(size_t)b * C + c]; }
+        for (int b = bl; b < nb; b += FIN_BL) { s += (double)ssum[(size_t)b * stride + c]; q += (double)ssq[(size_t)b * stride + c]; }
     s = fin_fold(s); q = fin_fold(q);
     if ((threadIdx.x & 63) < FIN_CL) { rs_[wv][cl] = s; rq_[wv][cl] = q; }
     __syncthreads();
@@ -1306,9 +1307,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 
 int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count, const float* gamma, const float* beta,
                           float eps, float momentum, float* moving_mean, float* moving_var, int training,
-                          float* mean, float* rstd, float* a, float* b, int C, hipStream_t s, float var_corr) {
+                          float* mean, float* rstd, float* a, float* b, int C, hipStream_t s, float var_corr, int stride) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CL - 1) / FIN_CL), dim3(FIN_CL * FIN_BL), 0, s, ssum, ssq, nb, count, gamma, beta, eps, momentum,
-                       moving_mean, moving_var, training, mean, rstd, a, b, C, var_corr);
+                       moving_mean, moving_var, training, mean, rstd, a, b, C, var_corr, stride ? stride : C);
     return LAUNCH_OK();
 }
 
@@ -1318,7 +1319,10 @@ int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count,
 // inf.part != nullptr (inference): the kernel also does what two launches did before it — the sum of the depthwise conv's partial statistic
 // rows (the sample's channel sums over time) and the BatchNorm constants from the moving statistics (a = gamma * rsqrt(mv + eps),
 // b = beta - mm * a) — so a Conv1DBlock's forward is 4 launches instead of 6 (configs[4]: B = 1, every launch is ~9 us of latency)
-struct EcaInfer { const float* part = nullptr; int prows = 0; const float* mm = nullptr; const float* mv = nullptr; const float* gamma = nullptr; const float* beta = nullptr; float eps = 0.f; };
+// inf.part != nullptr with inf.mm == nullptr (training, round 3): the partial rows are summed here too (the per-sample sums go to inf.gap_out
+// for the backward pass — the stats_reduce launch is gone), the BatchNorm constants come from bn_finalize (batch statistics) as before
+struct EcaInfer { const float* part = nullptr; int prows = 0; const float* mm = nullptr; const float* mv = nullptr; const float* gamma = nullptr; const float* beta = nullptr; float eps = 0.f;
+                  float* gap_out = nullptr; };
 __global__ __launch_bounds__(1024) void eca_fwd_kernel(const float* __restrict__ gap, const float* __restrict__ a, const float* __restrict__ bsh,
                                                       const float* __restrict__ w5, float invT, float* __restrict__ gn,
                                                       float* __restrict__ sg, float* __restrict__ P, float* __restrict__ Q, int C, float* __restrict__ rs, DropSpec dp, int dp_fold, EcaInfer inf) {
@@ -1334,16 +1338,21 @@ __global__ __launch_bounds__(1024) void eca_fwd_kernel(const float* __restrict__
                 const float* p = inf.part + ((size_t)b * inf.prows * 2) * C + cc;
                 float s0 = 0.f;
                 for (int r = 0; r < inf.prows; ++r) s0 += p[(size_t)(2 * r) * C];
-                const float aa = inf.gamma[cc] * rsqrtf(inf.mv[cc] + inf.eps), bb = inf.beta[cc] - inf.mm[cc] * aa;
-                al[cc] = aa; bl[cc] = bb;
-                g = aa * s0 * invT + bb;
+                if (inf.mm) {
+                    const float aa = inf.gamma[cc] * rsqrtf(inf.mv[cc] + inf.eps), bb = inf.beta[cc] - inf.mm[cc] * aa;
+                    al[cc] = aa; bl[cc] = bb;
+                    g = aa * s0 * invT + bb;
+                } else {
+                    inf.gap_out[(size_t)b * C + cc] = s0;
+                    g = a[cc] * s0 * invT + bsh[cc];
+                }
             } else g = a[cc] * gap[(size_t)b * C + cc] * invT + bsh[cc];
             gn[(size_t)b * C + cc] = g;
         }
         sh[c] = g;
     }
     __syncthreads();
-    if (inf.part) { a = al; bsh = bl; }
+    if (inf.part && inf.mm) { a = al; bsh = bl; }
     const float w0 = w5[0], w1 = w5[1], w2 = w5[2], w3 = w5[3], w4 = w5[4];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float z = w0 * sh[c] + w1 * sh[c + 1] + w2 * sh[c + 2] + w3 * sh[c + 3] + w4 * sh[c + 4];
@@ -1365,6 +1374,13 @@ __global__ __launch_bounds__(1024) void eca_fwd_kernel(const float* __restrict__
 int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
                    float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, float* rs, DropSpec dp, int dp_fold) {
     hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (C + 4) * sizeof(float), s, gap, a, b, w5, invT, gn, sgate, P, Q, C, rs, dp, dp_fold, EcaInfer{});
+    return LAUNCH_OK();
+}
+// training form over the depthwise conv's partial statistic rows: sums them per sample (-> gap_out [B, C]) and gates with bn_finalize's constants
+int launch_eca_fwd_part(const float* part, int prows, float* gap_out, const float* a, const float* b, const float* w5, float invT,
+                        float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, float* rs, DropSpec dp, int dp_fold) {
+    EcaInfer inf; inf.part = part; inf.prows = prows; inf.gap_out = gap_out;
+    hipLaunchKernelGGL(eca_fwd_kernel, dim3(B), dim3(256), (3 * C + 4) * sizeof(float), s, (const float*)nullptr, a, b, w5, invT, gn, sgate, P, Q, C, rs, dp, dp_fold, inf);
     return LAUNCH_OK();
 }
 int launch_eca_fwd_infer(const float* part, int prows, const float* mm, const float* mv, const float* gamma, const float* beta, float eps, const float* w5, float invT,

@@ -160,12 +160,15 @@ int launch_dwconv_bwd(int dt, int inop, const void* dy, const void* x, const flo
 // a = gamma*rstd, b = beta - mean*a ; moving statistics update when training
 int launch_bn_finalize(const float* ssum, const float* ssq, int nb, float count, const float* gamma, const float* beta,
                        float eps, float momentum, float* moving_mean, float* moving_var, int training,
-                       float* mean, float* rstd, float* a, float* b, int C, hipStream_t s, float var_corr = 1.f);   // var_corr: factor on the batch variance
-                                                                                                                       // entering moving_var (torch: n/(n-1))
+                       float* mean, float* rstd, float* a, float* b, int C, hipStream_t s, float var_corr = 1.f, int stride = 0);   // var_corr: factor on the batch variance
+                                                                                                                       // entering moving_var (torch: n/(n-1)); stride: floats between rows of ssum / ssq (0: C)
 // ECA fwd on [B,C]: g = a*gap/T + b ; s = sigmoid(conv5(g)) ; P = a*s ; Q = b*s
 int launch_eca_fwd(const float* gap, const float* a, const float* b, const float* w5, float invT,
                    float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, float* rs = nullptr, DropSpec dp = {0, 0, 1.f}, int dp_fold = 0);
 // rs != nullptr: the kernel also draws the per-sample drop-path scale rs[b] (dp) and, with dp_fold, scales P and Q by it
+// training form over the depthwise conv's partial statistic rows part[B][prows][2][C] (no stats_reduce launch): per-sample sums -> gap_out [B, C]
+int launch_eca_fwd_part(const float* part, int prows, float* gap_out, const float* a, const float* b, const float* w5, float invT,
+                        float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s, float* rs = nullptr, DropSpec dp = {0, 0, 1.f}, int dp_fold = 0);
 // inference form: the sample's channel sums come from the depthwise conv's partial rows, a / b from the BatchNorm's moving statistics
 int launch_eca_fwd_infer(const float* part, int prows, const float* mm, const float* mv, const float* gamma, const float* beta, float eps, const float* w5, float invT,
                          float* gn, float* sgate, float* P, float* Q, int B, int C, hipStream_t s);

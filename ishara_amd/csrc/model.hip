@@ -564,9 +564,14 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     // inside eca_fwd (4 launches per Conv1DBlock instead of 6: at B = 1 every launch is ~9 us of latency)
     int prows = 0;
     const bool infer_fused = !r.training && getenv("ISHARA_NO_INFER_FUSION") == nullptr;
+    static const bool no_train_fusion = getenv("ISHARA_NO_STATS_FUSION") != nullptr;
+    const bool train_fused = r.training && !no_train_fusion;
     CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_SWISH, m->W(cb.z1), m->P(cb.dw), nullptr, m->W(cb.h2), m->Wf(cb.ssum), m->Wf(cb.ssq), m->Wf(m->slab), B, T, c, cb.k, cb.k - 1, m->s,
-                                                                                          infer_fused ? &prows : nullptr));
-    if (!(infer_fused && prows > 0))
+                                                                                          (infer_fused || train_fused) ? &prows : nullptr));
+    if (train_fused && prows > 0)      // training: batch statistics straight from the partial rows [B * prows][2][C] (no stats_reduce launch; eca_fwd below sums them per sample)
+    CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(m->slab), m->Wf(m->slab) + c, B * prows, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
+                          m->P(cb.bn.mm), m->P(cb.bn.mv), r.training, m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.bsh), c, m->s, 1.f, 2 * c));
+    else if (!(infer_fused && prows > 0))
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(cb.ssum), m->Wf(cb.ssq), B, (float)B * T, m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, 0.95f,
                           m->P(cb.bn.mm), m->P(cb.bn.mv), r.training, m->Wf(cb.mean), m->Wf(cb.rstd), m->Wf(cb.a), m->Wf(cb.bsh), c, m->s));
     // Drop-path (c5:82-83) on the branch: y = x + rs[b] * (h4 W2 + b2).  Where the fast kernels apply, rs[b] is folded into the per-sample
@@ -585,6 +590,9 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
     if (infer_fused && prows > 0)
         CKP(m, "eca_fwd", 0, 0, launch_eca_fwd_infer(m->Wf(m->slab), prows, m->P(cb.bn.mm), m->P(cb.bn.mv), m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, m->P(cb.eca), 1.f / T,
                                                        m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s));
+    else if (train_fused && prows > 0)
+        CKP(m, "eca_fwd", 0, 0, launch_eca_fwd_part(m->Wf(m->slab), prows, m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s,
+                                                      ds.thr ? m->Wf(cb.rs) : nullptr, ds, cb.folded ? 1 : 0));
     else
     CKP(m, "eca_fwd", 0, 0, launch_eca_fwd(m->Wf(cb.ssum), m->Wf(cb.a), m->Wf(cb.bsh), m->P(cb.eca), 1.f / T, m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s, ds.thr ? m->Wf(cb.rs) : nullptr, ds, cb.folded ? 1 : 0));
     // h4 = h2 * P[b] + Q[b] (BatchNorm + ECA gate [+ drop-path]) as a prologue of the project GEMM: h2 is read once, h4 is written from
@@ -658,8 +666,16 @@ int confconv_fwd(ishara_model* m, ConfConv& c, const Run& r, const void* x) {
     const int dt = m->dt, d = m->d, B = r.B, T = m->T;
     OpArgs no; EpiArgs e0;
     CK(gemm_fwd(m, c.Wp1, x, dt, m->W(c.g), dt, r.M, OP_NONE, no, e0));
-    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), c.dwb >= 0 ? m->P(c.dwb) : nullptr, m->W(c.v), r.training ? m->Wf(c.ssum) : nullptr, r.training ? m->Wf(c.ssq) : nullptr, m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s));      // inference: no batch statistics
+    int prows = 0;
+    static const bool no_train_fusion = getenv("ISHARA_NO_STATS_FUSION") != nullptr;
+    const bool train_fused = r.training && !no_train_fusion;        // batch statistics straight from the depthwise conv's partial rows: no stats_reduce launch
+    CKP(m, "dwconv_fwd", 3.0 * r.M * m->d * (double)dt_size(m->dt), 0, launch_dwconv_fwd(dt, DWIN_GLU, m->W(c.g), m->P(c.dw), c.dwb >= 0 ? m->P(c.dwb) : nullptr, m->W(c.v), r.training ? m->Wf(c.ssum) : nullptr, r.training ? m->Wf(c.ssq) : nullptr, m->Wf(m->slab), B, T, d, c.k, (c.k - 1) / 2, m->s,
+                                                                                          train_fused ? &prows : nullptr));      // inference: no batch statistics
     const float var_corr = c.bn_unbiased && B * T > 1 ? (float)((double)B * T / ((double)B * T - 1.0)) : 1.f;
+    if (train_fused && prows > 0)
+    CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(m->slab), m->Wf(m->slab) + d, B * prows, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), c.bn_eps, c.bn_keep,
+                          m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s, var_corr, 2 * d));
+    else
     CKP(m, "bn_finalize", 0, 0, launch_bn_finalize(m->Wf(c.ssum), m->Wf(c.ssq), B, (float)B * T, m->P(c.bn.gamma), m->P(c.bn.beta), c.bn_eps, c.bn_keep,
                           m->P(c.bn.mm), m->P(c.bn.mv), r.training, m->Wf(c.mean), m->Wf(c.rstd), m->Wf(c.a), m->Wf(c.bsh), d, m->s, var_corr));
     CKP(m, "col_affine", 2.0 * r.M * d * (double)dt_size(m->dt), 0, launch_col_affine(dt, m->W(c.v), m->Wf(c.a), m->Wf(c.bsh), m->W(c.bnv), r.M, d, m->s));
