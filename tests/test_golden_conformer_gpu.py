@@ -259,3 +259,55 @@ def test_one_live_graph_per_encoder_and_eval_mode_gradients_are_errors():
         enc(x1)
     with torch.no_grad():
         enc(x1)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_product_encoder_at_reference_scale_vs_oracle(dt):
+    """dim 512, 8 heads (head dim 64), ffn x4, depthwise kernel 31, T = 384 — the scale the reference's commented-out training loop builds
+    (conformer.py:89-90 `ConformerEncoder(dim=512, num_layers=6, num_heads=8, expansion_factor=4, kernel_size=31, ...)`), 2 layers so that the fp64 oracle's training pass stays in seconds: output, input
+    gradient and every parameter gradient against the oracle restatement (pinned by the reference-run fixtures, which are d = 64)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import conformer_torch_oracle as RO
+    from ishara_amd.conformer import ConformerEncoder, default_state_dict
+    d, layers, heads, ksize, exp, B, T = 512, 2, 8, 31, 4, 2, 384
+    enc = ConformerEncoder(d, layers, heads, exp, ksize, 0.0, seq_len=T, max_batch=B, dtype=dt, seed=4)
+    g = np.random.default_rng(9)
+    sd = {k: v.numpy().copy() for k, v in enc.state_dict().items()}
+    for k in sd:                                    # non-trivial norms and biases
+        if "norm" in k and k.endswith("weight"): sd[k] = (1.0 + 0.2 * g.standard_normal(sd[k].shape)).astype(np.float32)
+        elif k.endswith("bias"): sd[k] = (0.1 * g.standard_normal(sd[k].shape)).astype(np.float32)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    P = {k: torch.from_numpy(v).double().requires_grad_(not k.endswith(("running_mean", "running_var"))) for k, v in sd.items()}
+    x = torch.from_numpy(g.standard_normal((B, T, d)).astype(np.float32))
+    Gm = torch.from_numpy(g.standard_normal((B, T, d)).astype(np.float32))
+    xo = x.double().requires_grad_(True)
+    yo, _ = RO.encoder(xo, P, layers, heads, training=True)
+    (yo * Gm.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = enc.train()(xg)
+    (y * Gm.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    yerr = float((y.detach().cpu().double() - yo.detach()).abs().max())
+    dx, want_dx = xg.grad.cpu().double(), xo.grad
+    if dt == "f32":
+        assert yerr <= 3e-4, yerr
+        assert float((dx - want_dx).abs().max()) <= 2e-3 * float(want_dx.abs().max())
+    else:
+        assert yerr <= 0.12, yerr
+        assert float((dx - want_dx).norm() / want_dx.norm()) <= 0.12
+    grads = enc.grad_state_dict()
+    gscale = max(float(v.grad.abs().max()) for v in P.values() if v.grad is not None)
+    bad = []
+    for k, v in P.items():
+        if v.grad is None: continue
+        want, got = v.grad.numpy(), grads[k].double().numpy()
+        if np.abs(want).max() < 1e-6 * gscale:
+            if np.abs(got).max() > (1e-3 if dt == "f32" else 3e-2) * gscale: bad.append((k, float(np.abs(got).max())))
+        elif dt == "f32":
+            e = float(np.abs(got - want).max() / np.abs(want).max())
+            if e > 3e-3: bad.append((k, e))
+        else:
+            e = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+            if e > 0.12: bad.append((k, e))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:10]

@@ -3,7 +3,7 @@
 shapes, for a per-kernel table under rocprofv3 (`rocprofv3 --kernel-trace --stats -- python tools/rfamily_bench.py squeezeformer`):
   squeezeformer: SqueezeformerEncoder(input_dim 80, encoder_dim 512, 16 layers, reduce 7 / recover 15, 8 heads, ffn x4, conv k 31) —
                  squeezeformer/encoder.py:30-46 — on B clips of T = 800 frames (199 frames after the conv2d subsampling)
-  conformer:     ConformerEncoder(dim 512, 7 layers? the reference leaves them to the caller: 12 layers, 8 heads, ffn x4, k 31) on T = 384
+  conformer:     ConformerEncoder(dim 512, 6 layers, 8 heads, ffn x4, k 31) — conformer/conformer.py:89-90 — on T = 384
 Prints ms per forward and per forward+backward (HIP events on the current stream); synthetic inputs, dropout at the reference default 0.1."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,7 @@ if kind == "squeezeformer":
 else:
     from ishara_amd import ConformerEncoder
     T, F = 384, 512
-    enc = ConformerEncoder(512, 12, 8, 4, 31, 0.1, seq_len=T, max_batch=B, dtype="bf16")
+    enc = ConformerEncoder(512, 6, 8, 4, 31, 0.1, seq_len=T, max_batch=B, dtype="bf16")
 x = torch.randn(B, T, F, device="cuda")
 enc.train()
 def ev(): return torch.cuda.Event(enable_timing=True)
