@@ -764,6 +764,7 @@ __global__ __launch_bounds__(256) void dwconv_reg8_kernel(const T* __restrict__ 
 // a whole time range and walks it in 32-row chunks through a 64-row LDS ring of TRANSFORMED inputs (fp32, Swish / GLU applied once per element):
 //   * no halo re-reads inside a range, the tap weights (K x 4 channels per thread) are loaded once per workgroup;
 //   * the next chunk's global loads are in flight while the current chunk is computed (two barriers per chunk);
+//   * (channel pairs as float2 / v_pk_fma_f32 were tried: forward depthwise conv 0.897 -> 1.087 ms/step — scalar FMAs stay)
 //   * thread = 4 channels x 4 consecutive rows, row-stationary accumulation (every ring row is read once per thread and feeds up to four outputs);
 //   * lane pairs swap halves (DPP quad_perm) so that every store is 16 bytes: an even lane writes 8 channels of rows 0 / 2, an odd lane of rows 1 / 3;
 //   * BatchNorm / GAP statistics: per-thread sums over the whole range, one partial row per workgroup at the end (deterministic, as before).
@@ -783,16 +784,15 @@ __global__ __launch_bounds__(256, 3) void dwconv_stream_kernel(const T* __restri
     const int per = ((Tn + tsplit - 1) / tsplit + CH - 1) / CH * CH;
     const int r_beg = blockIdx.z * per, r_end = min(Tn, r_beg + per);
     if (r_beg >= Tn) return;
-    // ---- compute mapping: 32 channel quads x 8 row groups of 4; channel PAIRS as float2 so that the tap products compile to v_pk_fma_f32
-    typedef __attribute__((ext_vector_type(2))) float sf2;
+    // ---- compute mapping: 32 channel quads x 8 row groups of 4
     const int cq = tid & 31, rg = tid >> 5;
     const int ch = c0 + cq * 4;
-    sf2 wr[K][2];
+    float wr[K][4];
 #pragma unroll
-    for (int j = 0; j < K; ++j) { float t4[4]; load4(w + (size_t)j * C + ch, t4); wr[j][0] = sf2{t4[0], t4[1]}; wr[j][1] = sf2{t4[2], t4[3]}; }
-    sf2 bv[2] = {sf2{0.f, 0.f}, sf2{0.f, 0.f}};
-    if (bias) { float t4[4]; load4(bias + ch, t4); bv[0] = sf2{t4[0], t4[1]}; bv[1] = sf2{t4[2], t4[3]}; }
-    sf2 s1[2] = {sf2{0.f, 0.f}, sf2{0.f, 0.f}}, s2[2] = {sf2{0.f, 0.f}, sf2{0.f, 0.f}};
+    for (int j = 0; j < K; ++j) load4(w + (size_t)j * C + ch, wr[j]);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) load4(bias + ch, bv);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     // ---- staging mapping: 16 chunks of 8 channels x 16 rows, two row sets per chunk of 32 rows
     const int sc = tid & 15, sr = tid >> 4;
     typedef __attribute__((ext_vector_type(4))) uint32_t raw4;
@@ -844,19 +844,20 @@ __global__ __launch_bounds__(256, 3) void dwconv_stream_kernel(const T* __restri
         const bool more = ti + CH - lag < r_end;
         if (more) gload(ti + CH);
         const int o0 = ti - lag + rg * 4;                 // first output row of this thread
-        sf2 acc[4][2];
+        float acc[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { acc[u][0] = sf2{0.f, 0.f}; acc[u][1] = sf2{0.f, 0.f}; }
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[u][e] = 0.f;
         // input rows o0 - padl .. o0 - padl + K + 2
 #pragma unroll
         for (int qd = 0; qd < K + 3; ++qd) {
             const int tin = o0 - padl + qd;
             const float4 rw = *reinterpret_cast<const float4*>(ring + ((tin & (RB - 1)) * CT) + cq * 4);
-            const sf2 r0 = sf2{rw.x, rw.y}, r1 = sf2{rw.z, rw.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = qd - u;
-                if (j >= 0 && j < K) { acc[u][0] += wr[j][0] * r0; acc[u][1] += wr[j][1] * r1; }
+                if (j >= 0 && j < K) { acc[u][0] += wr[j][0] * rw.x; acc[u][1] += wr[j][1] * rw.y; acc[u][2] += wr[j][2] * rw.z; acc[u][3] += wr[j][3] * rw.w; }
             }
         }
         // pack, swap halves inside lane pairs, 16-byte stores
@@ -864,10 +865,11 @@ __global__ __launch_bounds__(256, 3) void dwconv_stream_kernel(const T* __restri
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const bool live = o0 + u >= r_beg && o0 + u < r_end;
-            acc[u][0] += bv[0]; acc[u][1] += bv[1];
-            if (live) { s1[0] += acc[u][0]; s1[1] += acc[u][1]; s2[0] += acc[u][0] * acc[u][0]; s2[1] += acc[u][1] * acc[u][1]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[u][e] += bv[e]; if (live) { s1[e] += acc[u][e]; s2[e] += acc[u][e] * acc[u][e]; } }
             T tmp[4];
-            tmp[0] = from_f<T>(acc[u][0].x); tmp[1] = from_f<T>(acc[u][0].y); tmp[2] = from_f<T>(acc[u][1].x); tmp[3] = from_f<T>(acc[u][1].y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tmp[e] = from_f<T>(acc[u][e]);
             pk[u][0] = reinterpret_cast<const uint32_t*>(tmp)[0]; pk[u][1] = reinterpret_cast<const uint32_t*>(tmp)[1];
         }
         const bool odd = lane & 1;
@@ -889,8 +891,8 @@ __global__ __launch_bounds__(256, 3) void dwconv_stream_kernel(const T* __restri
         __syncthreads();
     }
     if (part) {      // one partial row per (sample, time range): part[B][P = tsplit][2][C]
-        sred[rg][0][cq * 4 + 0] = s1[0].x; sred[rg][0][cq * 4 + 1] = s1[0].y; sred[rg][0][cq * 4 + 2] = s1[1].x; sred[rg][0][cq * 4 + 3] = s1[1].y;
-        sred[rg][1][cq * 4 + 0] = s2[0].x; sred[rg][1][cq * 4 + 1] = s2[0].y; sred[rg][1][cq * 4 + 2] = s2[1].x; sred[rg][1][cq * 4 + 3] = s2[1].y;
+        sred[rg][0][cq * 4 + 0] = s1[0]; sred[rg][0][cq * 4 + 1] = s1[1]; sred[rg][0][cq * 4 + 2] = s1[2]; sred[rg][0][cq * 4 + 3] = s1[3];
+        sred[rg][1][cq * 4 + 0] = s2[0]; sred[rg][1][cq * 4 + 1] = s2[1]; sred[rg][1][cq * 4 + 2] = s2[2]; sred[rg][1][cq * 4 + 3] = s2[3];
         __syncthreads();
         if (tid < CT) {
             float a = 0.f, q = 0.f;
