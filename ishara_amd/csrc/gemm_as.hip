@@ -188,30 +188,7 @@ DEVI void as_pass(const as_t* __restrict__ A, const as_t* __restrict__ Bt, TC* _
         const int bsm = min(m_base, M - 1) / ea.T;                          // PRO 2: the workgroup's rows lie in ONE sample (launcher)
         const float* c0 = PRO == 1 ? ea.ln_gamma : ea.pa_P + (size_t)bsm * K;
         const float* c1 = PRO == 1 ? ea.ln_beta : ea.pa_Q + (size_t)bsm * K;
-        if (PRO == 2 && ea.eca_part) {         // inference: P, Q of the sample from the partial statistic rows (kernels.h EpiArgs::eca_*)
-            float* gb = cs + 2 * K;             // [K + 4]: BatchNorm output's time mean per channel, two zero channels on each side
-            const float* pr = ea.eca_part + ((size_t)bsm * ea.eca_prows * 2) * K;
-            for (int x = tid; x < K + 4; x += NW * 64) {
-                const int cc = x - 2;
-                float gv = 0.f;
-                if (cc >= 0 && cc < K) {
-                    float s0 = 0.f;
-                    for (int r = 0; r < ea.eca_prows; ++r) s0 += pr[(size_t)(2 * r) * K + cc];
-                    const float aa = ea.eca_gamma[cc] * rsqrtf(ea.eca_mv[cc] + ea.eca_eps), bb = ea.eca_beta[cc] - ea.eca_mm[cc] * aa;
-                    cs[cc] = aa; cs[K + cc] = bb;
-                    gv = aa * s0 * ea.eca_invT + bb;
-                }
-                gb[x] = gv;
-            }
-            __syncthreads();
-            const float w0 = ea.eca_w5[0], w1 = ea.eca_w5[1], w2 = ea.eca_w5[2], w3 = ea.eca_w5[3], w4 = ea.eca_w5[4];
-            for (int x = tid; x < K; x += NW * 64) {
-                const float sv = sigmoidf_(w0 * gb[x] + w1 * gb[x + 1] + w2 * gb[x + 2] + w3 * gb[x + 3] + w4 * gb[x + 4]);
-                cs[x] *= sv; cs[K + x] *= sv;
-            }
-        } else {
-            for (int x = tid; x < K; x += NW * 64) { cs[x] = c0[x]; cs[K + x] = c1[x]; }
-        }
+        for (int x = tid; x < K; x += NW * 64) { cs[x] = c0[x]; cs[K + x] = c1[x]; }
         __syncthreads();
         // Every pass over the fragments unpacks them again from the packed registers, behind an opaque asm: otherwise hipcc keeps
         // all 8*KT*RT unpacked floats alive across the three passes (statistics, variance, normalise) and spills hundreds of VGPRs.

@@ -48,12 +48,6 @@ struct EpiArgs {
     const float* pa_P = nullptr;      // per-sample affine: A' = A * pa_P[m / T, k] + pa_Q[m / T, k]   (BatchNorm + ECA gate of a Conv1DBlock)
     const float* pa_Q = nullptr;
     void* pro_out = nullptr;          // A' rows [M, K] in the operand type (null: not needed, inference)
-    // inference form of the per-sample affine (round 3; one launch less per Conv1DBlock at B = 1, where a launch is ~5 us of latency): eca_part != nullptr —
-    // the workgroup computes P, Q of its sample itself: channel sums from the depthwise conv's partial rows eca_part[B][eca_prows][2][K], BatchNorm
-    // constants from the moving statistics, the 5-tap ECA gate over the channel axis (what eca_fwd_kernel's inference form did in a launch of its own)
-    const float* eca_part = nullptr; int eca_prows = 0;
-    const float* eca_mm = nullptr; const float* eca_mv = nullptr; const float* eca_gamma = nullptr; const float* eca_beta = nullptr; const float* eca_w5 = nullptr;
-    float eca_eps = 0.f, eca_invT = 0.f;
     int head_major = 1;               // 1: cols = h*3dh + {q,k,v}*dh + i (TF path); 0: {q,k,v}*d + h*dh + i (torch twin)
     // A-stationary kernel only: C rows are ldc elements apart (0: N) and only the columns below n_valid are stored (0: all) — a 60-column
     // classifier runs as N = 64 over the zero-padded weight shadow (no residual / act' operands with these)

@@ -587,18 +587,7 @@ static int conv_fwd(ishara_model* m, ConvBlock& cb, const Run& r, const void* x)
                     gemm_tn_bias_rowscale_ok(dt, dt, dt, r.M, cb.W2.K, cb.W2.N, T);
         e2.rowscale_bias = cb.folded ? 1 : 0;
     }
-    // inference, A-stationary project GEMM with the per-sample-affine prologue: the GEMM's workgroups form P, Q of their sample themselves (EpiArgs::eca_*),
-    // no eca_fwd launch at all — 3 launches per Conv1DBlock
-    bool eca_in_gemm = false;
-    static const bool no_eca_in_gemm = getenv("ISHARA_NO_ECA_IN_GEMM") != nullptr;
-    if (infer_fused && prows > 0 && !no_eca_in_gemm) {
-        EpiArgs probe = e2; probe.pa_P = m->Wf(cb.P); probe.pa_Q = m->Wf(cb.Q); probe.T = T; probe.bias = m->P(cb.W2.b);
-        eca_in_gemm = gemm_nt_as_prologue_ok(dt, dt, dt, r.M, cb.W2.N, cb.W2.K, cb.W2.ldt, probe) && cb.W2.K == c && (size_t)(3 * c + 4) * 4 <= (size_t)16384;
-    }
-    if (eca_in_gemm) {
-        e2.eca_part = m->Wf(m->slab); e2.eca_prows = prows; e2.eca_mm = m->P(cb.bn.mm); e2.eca_mv = m->P(cb.bn.mv); e2.eca_gamma = m->P(cb.bn.gamma); e2.eca_beta = m->P(cb.bn.beta);
-        e2.eca_w5 = m->P(cb.eca); e2.eca_eps = 1e-3f; e2.eca_invT = 1.f / T;
-    } else if (infer_fused && prows > 0)
+    if (infer_fused && prows > 0)
         CKP(m, "eca_fwd", 0, 0, launch_eca_fwd_infer(m->Wf(m->slab), prows, m->P(cb.bn.mm), m->P(cb.bn.mv), m->P(cb.bn.gamma), m->P(cb.bn.beta), 1e-3f, m->P(cb.eca), 1.f / T,
                                                        m->Wf(cb.gn), m->Wf(cb.sg), m->Wf(cb.P), m->Wf(cb.Q), B, c, m->s));
     else if (train_fused && prows > 0)
