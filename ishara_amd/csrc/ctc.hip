@@ -2,6 +2,7 @@
 // blank = last class, logit_length = T) and the greedy decoder (c8:4-12).
 //
 // One workgroup per sample; the lattice has S = 2*len+1 <= 2L+1 states (see ctc_scaled_kernel).
+#include <type_traits>
 #include "kernels.h"
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
@@ -15,10 +16,12 @@ size_t ctc_workspace_floats(int B, int T, int L) { return 4 * (size_t)B * T * 64
 // the drift at the 1e-6 level while exp/log only ever see small-magnitude differences.  (A scaled PROBABILITY-space
 // recursion is not an option: the state vector of one frame spans > 250 decades on random logits, tools/ notes in DESIGN.md.)
 DEVI double lse3(double a, double b, double c) {
+    // branch-free: with all three terms dead (m = CTC_NEG) the exponentials are exp(0) and the result is discarded by the select — an early
+    // return was an exec-mask branch on the recursions' dependency chain
     const double m = fmax(a, fmax(b, c));
-    if (m <= -1e29) return CTC_NEG;
     const float sum = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
-    return m + (double)__logf(sum);
+    const double r = m + (double)__logf(sum);
+    return m <= -1e29 ? CTC_NEG : r;
 }
 DEVI double shfl_up_d(double v, int d) { return __shfl_up(v, d, 64); }
 DEVI double shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
@@ -65,17 +68,21 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     __syncthreads();
     const int len = s_len, S = 2 * len + 1;
 
-    if (tid < 128) {
+    // The recursions, instantiated for a COMPILE-TIME number NK of occupied state registers per lane (1: labels of up to 31 symbols, 2: up to 63)
+    // so that the per-k loops are straight-line code; NK = 0 keeps the run-time count (longer labels).  The block picks its instantiation below.
+    auto recursions = [&](auto nkc) {
+        constexpr int NK = decltype(nkc)::value;
+        constexpr int KM = NK ? NK : NS;
         const int wave = tid >> 6;
         // state s = lane + 64 k (k < NS): a label of up to 31 symbols (S <= 63) occupies k = 0 only, and the recursion skips the
         // other k (wave-uniform nk) -- a third of the work of NS consecutive states per lane; lattice rows are written as
         // contiguous 512-byte pieces.  The s-1 / s-2 neighbours come from lanes l-1 / l-2 by a rotation; lanes 0 (and 1) take
         // them from lanes 63 (and 62) of the previous k.
-        const int nk = (S + 63) >> 6;
+        const int nk = NK ? NK : ((S + 63) >> 6);
         bool act[NS], skip_bw[NS], skip_fw[NS];
         int my[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
+        for (int k = 0; k < KM; ++k) {
             const int s = lane + 64 * k;
             my[k] = ext[s];
             act[k] = s < S;
@@ -90,8 +97,8 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             for (int u = 0; u < 8; ++u) {
                 const int t = min(max(t0 + dir * u, 0), Tn - 1);
 #pragma unroll
-                for (int k = 0; k < NS; ++k)
-                    if (k < nk) dst[u][k] = lg[(size_t)t * C + my[k]];
+                for (int k = 0; k < KM; ++k)
+                    if (NK != 0 || k < nk) dst[u][k] = lg[(size_t)t * C + my[k]];
             }
         };
         // emission log-probabilities of a gathered group, one group later: the loads have landed by then (the empty asm keeps the
@@ -101,18 +108,18 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             for (int u = 0; u < 8; ++u) {
                 const float ls = lse[min(max(t0 + dir * u, 0), Tn - 1)];
 #pragma unroll
-                for (int k = 0; k < NS; ++k)
-                    if (k < nk) { asm volatile("" : "+v"(src[u][k])); dst[u][k] = src[u][k] - ls; }
+                for (int k = 0; k < KM; ++k)
+                    if (NK != 0 || k < nk) { asm volatile("" : "+v"(src[u][k])); dst[u][k] = src[u][k] - ls; }
             }
         };
       if (wave == 0) {
         // ---- alpha ----
         double a[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
+        for (int k = 0; k < KM; ++k) {
             const int s = lane + 64 * k;
             a[k] = (act[k] && (s == 0 || (s == 1 && len > 0))) ? (double)(lg[my[k]] - lse[0]) : CTC_NEG;
-            if (k < nk) Gw[s] = a[k];
+            if (NK != 0 || k < nk) Gw[s] = a[k];
         }
         gather(1, 1, emn);
         settle(1, 1, emn, em);
@@ -124,11 +131,11 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                 if (t < Tn) {
                     double r1[NS], r2[NS], n[NS];
 #pragma unroll
-                    for (int k = 0; k < NS; ++k)
-                        if (k < nk) { r1[k] = __shfl(a[k], (lane + 63) & 63, 64); r2[k] = __shfl(a[k], (lane + 62) & 63, 64); }
+                    for (int k = 0; k < KM; ++k)
+                        if (NK != 0 || k < nk) { r1[k] = __shfl(a[k], (lane + 63) & 63, 64); r2[k] = __shfl(a[k], (lane + 62) & 63, 64); }
 #pragma unroll
-                    for (int k = 0; k < NS; ++k)
-                        if (k < nk) {
+                    for (int k = 0; k < KM; ++k)
+                        if (NK != 0 || k < nk) {
                             const double a1 = lane >= 1 ? r1[k] : (k >= 1 ? r1[k >= 1 ? k - 1 : 0] : CTC_NEG);
                             const double a2 = lane >= 2 ? r2[k] : (k >= 1 ? r2[k >= 1 ? k - 1 : 0] : CTC_NEG);
                             double v = act[k] ? lse3(a[k], a1, skip_bw[k] ? a2 : CTC_NEG) : CTC_NEG;
@@ -136,8 +143,8 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                             n[k] = v;
                         }
 #pragma unroll
-                    for (int k = 0; k < NS; ++k)
-                        if (k < nk) { a[k] = n[k]; Gw[(size_t)t * SP + lane + 64 * k] = n[k]; }
+                    for (int k = 0; k < KM; ++k)
+                        if (NK != 0 || k < nk) { a[k] = n[k]; Gw[(size_t)t * SP + lane + 64 * k] = n[k]; }
                 }
             }
             if (t0 + 8 < Tn) settle(t0 + 8, 1, emn, em);
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
         {
             double cand = CTC_NEG, cand2 = CTC_NEG;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {
+            for (int k = 0; k < KM; ++k) {
                 const int s = lane + 64 * k;
                 if (s == S - 1) cand = a[k];
                 if (s == S - 2 && len > 0) cand2 = a[k];
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
         // ---- beta (with emission): bt = beta_{t+1}; stores bsum_t[s] = logsumexp of the successors' betas ----
         double bt[NS];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) bt[k] = CTC_NEG;
+        for (int k = 0; k < KM; ++k) bt[k] = CTC_NEG;
         gather(Tn - 1, -1, emn);
         settle(Tn - 1, -1, emn, em);
         for (int tb = Tn - 1; tb >= 0; tb -= 8) {
@@ -177,28 +184,28 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
                     double bsum[NS];
                     if (t == Tn - 1) {
 #pragma unroll
-                        for (int k = 0; k < NS; ++k) {
+                        for (int k = 0; k < KM; ++k) {
                             const int s = lane + 64 * k;
                             bsum[k] = (act[k] && (s == S - 1 || (s == S - 2 && len > 0))) ? 0.0 : CTC_NEG;
                         }
                     } else {
                         double d1[NS], d2[NS];
 #pragma unroll
-                        for (int k = 0; k < NS; ++k)
-                            if (k < nk) { d1[k] = __shfl(bt[k], (lane + 1) & 63, 64); d2[k] = __shfl(bt[k], (lane + 2) & 63, 64); }
+                        for (int k = 0; k < KM; ++k)
+                            if (NK != 0 || k < nk) { d1[k] = __shfl(bt[k], (lane + 1) & 63, 64); d2[k] = __shfl(bt[k], (lane + 2) & 63, 64); }
 #pragma unroll
-                        for (int k = 0; k < NS; ++k)
-                            if (k < nk) {
+                        for (int k = 0; k < KM; ++k)
+                            if (NK != 0 || k < nk) {
                                 // successors s+1 / s+2: lanes 63 (and 62) take them from lanes 0 (and 1) of the next k (absent: no state)
-                                const bool nx = k + 1 < NS && k + 1 < nk;
-                                const double b1 = lane <= 62 ? d1[k] : (nx ? d1[k + 1 < NS ? k + 1 : k] : CTC_NEG);
-                                const double b2 = lane <= 61 ? d2[k] : (nx ? d2[k + 1 < NS ? k + 1 : k] : CTC_NEG);
+                                const bool nx = k + 1 < KM && k + 1 < nk;
+                                const double b1 = lane <= 62 ? d1[k] : (nx ? d1[k + 1 < KM ? k + 1 : k] : CTC_NEG);
+                                const double b2 = lane <= 61 ? d2[k] : (nx ? d2[k + 1 < KM ? k + 1 : k] : CTC_NEG);
                                 bsum[k] = act[k] ? lse3(bt[k], b1, skip_fw[k] ? b2 : CTC_NEG) : CTC_NEG;
                             }
                     }
 #pragma unroll
-                    for (int k = 0; k < NS; ++k)
-                        if (k < nk) {
+                    for (int k = 0; k < KM; ++k)
+                        if (NK != 0 || k < nk) {
                             Hw[(size_t)t * SP + lane + 64 * k] = bsum[k];
                             bt[k] = bsum[k] > -1e29 ? bsum[k] + (double)em[u][k] : CTC_NEG;
                         }
@@ -207,6 +214,12 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
             if (tb - 8 >= 0) settle(tb - 8, -1, emn, em);
         }
       }
+    };
+    if (tid < 128) {
+        const int nkb = (S + 63) >> 6;
+        if (NS >= 2 && nkb == 1) recursions(std::integral_constant<int, 1>{});
+        else if (NS >= 3 && nkb == 2) recursions(std::integral_constant<int, 2>{});
+        else recursions(std::integral_constant<int, 0>{});
     }
     __threadfence_block();
     __syncthreads();
