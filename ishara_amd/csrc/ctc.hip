@@ -57,21 +57,12 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     __shared__ double s_logp;
 
     if (tid == 0) { int n = 0; for (int i = 0; i < L; ++i) n += (lab[i] != blank) ? 1 : 0; s_len = n; }
-    // row log-sum-exp: a wavefront per frame (lane = class: one coalesced 240-byte load per frame instead of a thread walking its own row of 60 floats),
-    // eight frames of a wave in flight; C <= 64 (launcher)
-    {
-        const int lane0 = tid & 63, wv0 = tid >> 6;
-        for (int t0 = wv0; t0 < Tn; t0 += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int t = min(t0 + 4 * u, Tn - 1); v[u] = lane0 < C ? lg[(size_t)t * C + lane0] : -INFINITY; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float m = wave_max(v[u]);
-                const float a = wave_sum(lane0 < C ? expf(v[u] - m) : 0.f);
-                if (lane0 == 0 && t0 + 4 * u < Tn) lse[t0 + 4 * u] = m + logf(a);
-            }
-        }
+    for (int t = tid; t < Tn; t += 256) {
+        float m = -1e30f;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, lg[(size_t)t * C + c]);
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += expf(lg[(size_t)t * C + c] - m);
+        lse[t] = m + logf(a);
     }
     for (int s = tid; s < SP; s += 256) ext[s] = (s < 2 * L + 1 && (s & 1)) ? (int)lab[s >> 1] : blank;
     __syncthreads();
@@ -236,59 +227,50 @@ __global__ __launch_bounds__(256) void ctc_kernel(const float* __restrict__ logi
     // a (frame, class) thread looping over the states was O(T*C*S) and took longer than both recursions), then the gradient
     if (dlogits) {
         // four frames of a wave in flight together: the loop used to wait out one L2 round trip per frame (96 dependent trips per wave)
-        __shared__ float cls[4][8][64];
+        constexpr int U = 4;
+        __shared__ float cls[4][U][64];
         const double logp = s_logp;
         float* dl = dlogits + (size_t)b * Tn * C;
         const int wv = tid >> 6;
-        // U frames of a wave in flight together (the loop used to wait out one L2 round trip per frame, 96 dependent trips per wave); the number of
-        // occupied state registers per lane is a compile-time constant per instantiation, as in the recursions
-        auto posterior = [&](auto nkc, auto uc) {
-            constexpr int NK = decltype(nkc)::value, U = decltype(uc)::value;
-            constexpr int KM = NK ? NK : NS;
-            for (int t0 = wv; t0 < Tn; t0 += 4 * U) {
-                double al[U][KM], bs[U][KM];
-                float lgv[U];
+        for (int t0 = wv; t0 < Tn; t0 += 4 * U) {
+            double al[U][NS], bs[U][NS];
+            float lgv[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int t = min(t0 + 4 * u, Tn - 1);
-                    cls[wv][u][lane] = 0.f;
-                    const double* ga = Gw + (size_t)t * SP;
-                    const double* gb = Hw + (size_t)t * SP;
+            for (int u = 0; u < U; ++u) {
+                const int t = min(t0 + 4 * u, Tn - 1);
+                cls[wv][u][lane] = 0.f;
+                const double* ga = Gw + (size_t)t * SP;
+                const double* gb = Hw + (size_t)t * SP;
 #pragma unroll
-                    for (int k = 0; k < KM; ++k) {
-                        const int s = lane + 64 * k;              // strided: coalesced 512-byte reads of the lattice rows
-                        al[u][k] = s < S ? ga[s] : CTC_NEG; bs[u][k] = s < S ? gb[s] : CTC_NEG;
-                    }
-                    lgv[u] = lane < C ? lg[(size_t)t * C + lane] : 0.f;
+                for (int k = 0; k < NS; ++k) {
+                    const int s = lane + 64 * k;              // strided: coalesced 512-byte reads of the lattice rows
+                    al[u][k] = s < S ? ga[s] : CTC_NEG; bs[u][k] = s < S ? gb[s] : CTC_NEG;
                 }
+                lgv[u] = lane < C ? lg[(size_t)t * C + lane] : 0.f;
+            }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int t = t0 + 4 * u;
-                    if (t >= Tn) continue;                        // wave-uniform
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + 4 * u;
+                if (t >= Tn) continue;                        // wave-uniform
 #pragma unroll
-                    for (int k = 0; k < KM; ++k) {
-                        const int s = lane + 64 * k;
-                        if (s < S && al[u][k] > -1e29 && bs[u][k] > -1e29 && logp > -1e29) atomicAdd(&cls[wv][u][ext[s]], __expf((float)(al[u][k] + bs[u][k] - logp)));
-                    }
-                    float gv = 0.f;
-                    if (lane < C) {
-                        const float sm = expf(lgv[u] - lse[t]);
-                        gv = grad_scale * (sm - cls[wv][u][lane]);
-                        dl[(size_t)t * C + lane] = gv;
-                    }
-                    if (dlb) {      // bf16 copy of the row, zero padded to 128 classes (MFMA operand of the classifier's dgrad / wgrad)
-                        const float lo = __shfl(gv, (2 * lane) & 63, 64), hi = __shfl(gv, (2 * lane + 1) & 63, 64);
-                        typedef __attribute__((ext_vector_type(2))) __bf16 ctc_bf2;
-                        ctc_bf2 pk; pk[0] = (__bf16)(lane < 32 ? lo : 0.f); pk[1] = (__bf16)(lane < 32 ? hi : 0.f);
-                        dlb[((size_t)b * Tn + t) * 64 + lane] = __builtin_bit_cast(uint32_t, pk);
-                    }
+                for (int k = 0; k < NS; ++k) {
+                    const int s = lane + 64 * k;
+                    if (s < S && al[u][k] > -1e29 && bs[u][k] > -1e29 && logp > -1e29) atomicAdd(&cls[wv][u][ext[s]], __expf((float)(al[u][k] + bs[u][k] - logp)));
+                }
+                float gv = 0.f;
+                if (lane < C) {
+                    const float sm = expf(lgv[u] - lse[t]);
+                    gv = grad_scale * (sm - cls[wv][u][lane]);
+                    dl[(size_t)t * C + lane] = gv;
+                }
+                if (dlb) {      // bf16 copy of the row, zero padded to 128 classes (MFMA operand of the classifier's dgrad / wgrad)
+                    const float lo = __shfl(gv, (2 * lane) & 63, 64), hi = __shfl(gv, (2 * lane + 1) & 63, 64);
+                    typedef __attribute__((ext_vector_type(2))) __bf16 ctc_bf2;
+                    ctc_bf2 pk; pk[0] = (__bf16)(lane < 32 ? lo : 0.f); pk[1] = (__bf16)(lane < 32 ? hi : 0.f);
+                    dlb[((size_t)b * Tn + t) * 64 + lane] = __builtin_bit_cast(uint32_t, pk);
                 }
             }
-        };
-        const int nkb = (S + 63) >> 6;
-        if (NS >= 2 && nkb == 1) posterior(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
-        else if (NS >= 3 && nkb == 2) posterior(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
-        else posterior(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+        }
     }
 }
 
