@@ -157,6 +157,8 @@ int ishara_dropout_mask(uint32_t seed, uint32_t site, int32_t rows, int32_t cols
  * (defaults: LDS-DMA NT, transposed-read TN, register-window depthwise conv); bits 4-11 ablation switches */
 /* switches of the A-stationary GEMM (1 paired half-line stores, 2 non-temporal side outputs, 16 chunked K = 256 form); -1 = library default */
 int ishara_debug_set_as_flags(int32_t flags);
+/* 0: never use the 256 x 256 two-operand tile GEMM (gemm_big.hip) — A/B runs against the A-stationary kernel inside one process; 1: library default */
+int ishara_debug_set_nt_big(int32_t on);
 int ishara_debug_force_regstage(int32_t on);
 
 /* ---- single-operator entry points (parity tests of the individual kernels) ------------ */

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ishara_ctc_loss": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _F, _P, _P]),
     "ishara_dropout_mask": (C.c_int, [_U32, _U32, _I32, _I32, _F, _P, _P]),
     "ishara_debug_set_as_flags": (C.c_int, [_I32]),
+    "ishara_debug_set_nt_big": (C.c_int, [_I32]),
     "ishara_debug_force_regstage": (C.c_int, [_I32]),
     "ishara_op_scratch_bytes": (_I64, [_I32, _I32, _I32]),
     "ishara_op_dense_fwd": (C.c_int, [_I32, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),

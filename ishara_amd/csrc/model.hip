@@ -1060,6 +1060,8 @@ static int g_dbg_epi = 0;
 extern int g_as_flags_override;
 // A-stationary GEMM switches (gemm_as.hip as_default_flags: 1 paired half-line stores, 2 non-temporal side outputs, 16 chunked K = 256 form); -1: library default
 extern "C" int ishara_debug_set_as_flags(int32_t flags) { g_as_flags_override = flags; return 0; }
+extern int g_nt_big;
+extern "C" int ishara_debug_set_nt_big(int32_t on) { g_nt_big = on; return 0; }
 extern "C" int ishara_debug_force_regstage(int32_t on) { g_force_regstage = (on & 1) ? 1 : ((on >> 3) & 1 ? 2 : ((on >> 13) & 1 ? 3 : 0)); g_dbg_epi = (on >> 4) & 15; g_dbg_tn = (on >> 8) & 31; g_force_tn_regstage = (on >> 1) & 1; g_force_dw_lds = (on >> 2) & 1; { const int tb = (on >> 14) & 3; g_tn_blocks = tb == 1 ? 256 : (tb == 2 ? 512 : (tb == 3 ? 768 : 0)); } g_attn_bwd_two_pass = (on >> 16) & 1; return 0; }
 
 extern "C" int ishara_preprocess(const float* raw, const int32_t* n_frames, int32_t max_frames, const float* mean, const float* stdv,

@@ -141,6 +141,44 @@ def test_dense_chunked_a_stationary_kernel(lib, M, K, N, act, with_resid):
     close(outs[51][rows.cuda()], ref, "dense_chunked", **TOL["bf16"])
 
 
+@pytest.mark.parametrize("M,K,N,act,with_resid", [(32768, 512, 512, 0, False), (32768, 1024, 512, 1, True), (32768 + 256, 512, 1024, 2, True), (34816, 640, 768, 0, True)])
+def test_dense_big_tile_kernel(lib, M, K, N, act, with_resid):
+    """The 256 x 256 two-operand tile GEMM (gemm_big.hip: K, N >= 512, M >= 32768 rows in whole 256-row tiles — config #4's shapes) against
+    the A-stationary / tile kernels it replaces there (ishara_debug_set_nt_big(0)) on every element, and against the fp64 reference on
+    sampled rows.  Same MFMA instruction and the same ascending order over K, so the fp32 accumulators agree bit for bit and the outputs
+    differ by at most one bf16 rounding of the epilogue arithmetic.  K = 640: an uneven split of K steps between main loop and tail;
+    M = 34816: a row-tile count that is not a multiple of 8 (the plain workgroup order)."""
+    code, tdt = DT["bf16"]
+    g = torch.Generator().manual_seed(M + N + K + act)
+    x = torch.randn(M, K, generator=g).to(tdt)
+    W = torch.randn(K, N, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).to(tdt) if with_resid else None
+    xd, Wd, bd = x.cuda().contiguous(), dev(W), dev(b)
+    rd = r.cuda().contiguous() if with_resid else None
+    sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
+    scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    outs = {}
+    try:
+        for on in (0, 1):
+            lib.ishara_debug_set_nt_big(on)
+            y = torch.empty(M, N, dtype=tdt, device="cuda")
+            _lib.check(lib.ishara_op_dense_fwd_ex(code, _lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(y), M, K, N, act, scp, stream()))
+            torch.cuda.synchronize()
+            outs[on] = y
+    finally:
+        lib.ishara_debug_set_nt_big(1)
+    d = (outs[0].float() - outs[1].float()).abs()
+    tol = 2.0 ** -7 * outs[0].float().abs().clamp_min(1.0)          # one bf16 ulp of the larger magnitude
+    assert bool((d <= tol).all()), f"big tile vs A-stationary: max diff {d.max().item()} at {int(d.argmax())}"
+    rows = torch.cat([torch.arange(0, 600), torch.arange(M // 2 - 200, M // 2 + 200), torch.arange(M - 400, M)])
+    ref = x[rows].double() @ W.to(tdt).double() + b.double()
+    ref = [ref, ref * torch.sigmoid(ref), torch.relu(ref)][act]
+    if with_resid:
+        ref = ref + r[rows].double()
+    close(outs[1][rows.cuda()], ref, "dense_big", **TOL["bf16"])
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,Cc", [(100, 64), (1000, 256), (77, 512)])
 def test_layernorm(lib, dt, M, Cc):
