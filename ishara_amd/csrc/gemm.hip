@@ -771,11 +771,12 @@ static int run_nt_op(int op, const void* A, const void* Bt, void* C, int M, int 
 // name of the kernel launch_gemm_nt / launch_gemm_tn will pick (profiler keys = rocprof kernel names)
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
 const char* gemm_nt_as_name(int dtC, int K, const EpiArgs& ea, int M, int N);
-const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb);
 int g_force_regstage = 0;   // NT kernel choice: 0 A-stationary kernel (gemm_as.hip) where it applies, else the 128x128 LDS-DMA tile kernel; 3 tile kernel only; 2 LDS-DMA 64x128 kernel; 1 register-staged
 bool gemm_nt_as_applicable(int dtC, int M, int N, int K, int ldb, const EpiArgs& ea);
 int launch_gemm_nt_as(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s);
 int launch_gemm_nt_as_f16(int dtC, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s);
+int gemm_tn_big_plan(int M, int Ka, int Nb, int* splits_out);
+int launch_gemm_tn_big(const void* A, const void* B, float* slab, int want_bias, int M, int Ka, int Nb, int* splits_out, const float* brs, int brsT, hipStream_t s);
 bool gemm_nt_big_applicable(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
 int launch_gemm_nt_big(int dtA, int dtM, int dtC, int op, const void* A, const void* Bt, void* C, int M, int N, int K, int ldb, const EpiArgs& ea, hipStream_t s);
 int g_dbg_tn = 0;           // ablation bits for the TN kernel: 1 skip MFMA, 2 skip LDS stores, 4 skip global loads
@@ -1679,6 +1680,19 @@ bool gemm_tn_psa_ok(int dtA, int dtB, int dtM, int M, int Ka, int Nb, int T) {
 
 static int run_tn_tr(const void* A, const void* B, float* out, float* dbias, float* slab, int M, int Ka, int Nb, hipStream_t s, int ka_valid, int nb_valid,
                      const float* brs, int brsT, TnDefer* defer, const TnPsa* psa) {
+    if (!psa && (!brs || (brsT > 0 && brsT % 128 == 0)) && !g_dbg_tn && !g_tn_blocks && ka_valid == Ka && !nb_valid) {
+        // config #4's shapes (Ka, Nb >= 512 in whole 256-wide tiles, M >= 32768): the 256 x 256 tile kernel of gemm_big.hip, sums right behind it
+        int bsplits = 0;
+        if (gemm_tn_big_plan(M, Ka, Nb, &bsplits) > 0) {
+            launch_gemm_tn_flush(defer, s);
+            if (g_tn_phase != 2) {
+                const int rc = launch_gemm_tn_big(A, B, slab, dbias ? 1 : 0, M, Ka, Nb, &bsplits, (brs && dbias) ? brs : nullptr, brsT, s);
+                if (rc != 0) return rc == 1 ? -2 : rc;
+            }
+            if (g_tn_phase != 1) launch_reduce_slabs2(slab, out, Ka * Nb, dbias, dbias ? Nb : 0, bsplits, (size_t)Ka * Nb + Nb, s, 0, 0);
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
+    }
     const int tiles = (Ka / 128) * (Nb / 128);
     const TnPsa nopsa = {};
     // workgroups: one per CU for up to 8 tiles (same kernel time as two per CU, half the slab bytes: the slab sums go
@@ -1959,7 +1973,8 @@ const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A
     if (dtM == DT_F32) return "gemm_nt_kernel<f32,f32,f32>";
     return dtC == DT_F32 ? "gemm_nt_kernel<bf16,bf16,f32>" : "gemm_nt_kernel<bf16,bf16,bf16>";
 }
-const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb) {
+const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb, bool brs) {
+    { int bs = 0; if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && opA == OP_NONE && opB == OP_NONE && !g_force_tn_regstage && !g_dbg_tn && !g_tn_blocks && gemm_tn_big_plan(M, Ka, Nb, &bs) > 0) return "gemm_tn_big_kernel"; }
     if (dtA == DT_BF16 && dtB == DT_BF16 && dtM == DT_BF16 && opA == OP_NONE && opB == OP_NONE && M % 64 == 0 && Ka % 128 == 0 && Nb % 128 == 0 &&
         M >= 256 && !g_force_tn_regstage) return "gemm_tn_tr_kernel<0>";
     return dtM == DT_F32 ? "gemm_tn_kernel<f32,f32,f32>" : (dtA == DT_F32 ? "gemm_tn_kernel<f32,bf16,bf16>" : (dtB == DT_F32 ? "gemm_tn_kernel<bf16,f32,bf16>" : "gemm_tn_kernel<bf16,bf16,bf16>"));

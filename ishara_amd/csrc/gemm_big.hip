@@ -224,6 +224,235 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const bf16* __restr
 #undef BG_EPI
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The weight-gradient (TN) form of the same tile: dW[Ka, Nb] (+)= A[M, Ka]^T . B[M, Nb], split over M, one 256 x 256 output tile and one
+// M-split per workgroup, the partial tile written to the caller's fp32 slab (summed by the caller: launch_reduce_slabs2).
+//
+// Why: the 128 x 128 tile kernel (gemm.hip gemm_tn_tr_kernel) has 16 - 32 workgroups per M-split at d = 512 that all request the same operand
+// rows; each keeps its own copy in flight in LDS, so of the 96 KB a CU has in flight only a quarter is distinct bytes, and the kernel runs at
+// 2.9 TB/s of operand bytes whatever the L2 does (tools/tn_traffic.py: pacing the sibling workgroups so that L2 serves every re-read brought the
+// fetched bytes from 1.7x to 1.0x of the operands and left the time unchanged).  With 256 x 256 tiles there are 4 - 16 workgroups per split.
+//
+// The K steps are 64 ROWS of the operands; a row is contiguous along the OUTPUT dimension, so the fragments (8 consecutive rows of one column per
+// lane) come from transposing LDS reads (ds_read_b64_tr_b16), image and swizzle as in gemm_tn_tr_kernel: [32 rows][256 B] blocks per 128
+// columns, 32-byte column blocks XOR tr_f(row).  Half tile a of an operand = its columns 128a .. 128a + 127 = [2 k-steps][32 rows][256 B] = 16 KB;
+// phases, request schedule, counted waits and the stagger of the two wave groups are those of gemm_nt_big_kernel.
+// Bias gradient: column sums of the B fragments by vector adds in the workgroups of output-row tile 0 (waves of the upper row group).
+DEVI int bg_tr_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+typedef __attribute__((ext_vector_type(2))) unsigned bg_u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned bg_u32x4t;
+
+template <bool IS_B>
+DEVI void bg_tn_stage(const BgSrc& g, char* smem, int parity, int half, int tt, int Ka, int Nb, int wid) {
+    const size_t off = (size_t)tt * 64 * (IS_B ? Nb : Ka) + (size_t)half * 128;
+    char* dst = smem + (IS_B ? 65536 : 0) + parity * 32768 + half * BG_HALF + wid * 1024;          // layout: A buffer 0 | A buffer 1 | B buffer 0 | B buffer 1 (the buffer is an instruction offset of the fragment reads)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((IS_B ? g.b[u] : g.a[u]) + off),
+                                         (__attribute__((address_space(3))) void*)(dst + u * 8192), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_big_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, float* __restrict__ slab, int want_bias,
+                                                              int M, int Ka, int Nb, int rows_per_split, int tiles, int nsplits, const float* __restrict__ brs, int brsT) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x 64 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int nNt = Nb >> 8;
+    int tile, split;
+    {       // the output tiles of one M-split read the same rows: back to back on ONE XCD
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        if ((nsplits & 7) == 0) { split = (j / tiles) * 8 + xcd; tile = j % tiles; }
+        else { split = id / tiles; tile = id % tiles; }
+    }
+    const int kt = tile / nNt, nt = tile % nNt;
+    const int k0 = kt << 8, n0 = nt << 8;
+    const int m_beg = split * rows_per_split;
+    const int T = rows_per_split >> 6;          // K steps of 64 rows (even: launcher)
+    const size_t sstride = (size_t)Ka * Nb + Nb;
+
+    BgSrc g;        // DMA instruction u of a half tile moves the four rows 4 (8u + wid) .. + 3 of the K step: 16 slots of 16 bytes per row
+    {
+        const int r = lane >> 4, sp = lane & 15;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = 4 * (8 * u + wid) + r;
+            const int col = (((sp >> 1) ^ bg_tr_f(row)) << 4) + ((sp & 1) << 3);      // logical column of physical slot sp
+            g.a[u] = A + (size_t)(m_beg + row) * Ka + k0 + col;
+            g.b[u] = B + (size_t)(m_beg + row) * Nb + n0 + col;
+        }
+    }
+    // transposing fragment reads: lane (g, q, p) addresses row 8g + q (+4 at +1024, +32 at +8192), 8 bytes at p of the 32-byte column block
+    unsigned fa[4], fb[2];              // [16-column block]: LDS byte addresses in buffer 0
+    {
+        const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, r0 = 8 * gq + q;
+        const unsigned base = (unsigned)(uintptr_t)smem + r0 * 256 + (pp << 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = base + (((wr * 4 + i) ^ bg_tr_f(r0)) << 5);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = base + 65536 + (((wc * 2 + j) ^ bg_tr_f(r0)) << 5);
+    }
+
+    f32x4 acc[2][2][4][2];
+    float csum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // bias gradient: this lane's share (rows 8g .. 8g + 7 of every 32) of the column sums of B columns n0 + 128b + 32wc + 16j + (lane & 15)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const bool bias_wave = want_bias && kt == 0 && wr == 0;
+    // brs != nullptr: the bias gradient is the column sum of brs[m / brsT] * B[m, :] (the drop-path scale of the sample a row belongs to;
+    // brsT % 128 == 0: the two K steps of a loop iteration lie in one sample) — the scale is a scalar register, reloaded at sample boundaries
+    float bsc = 1.f;
+    int brow = 0, bidx = 0;
+    if (brs) { bidx = m_beg / brsT; brow = m_beg - bidx * brsT; bsc = brs[bidx]; }
+    bg_u32x4t af[4][2], bf0[2][2], bf1[2][2];       // [block][k-step of 32 rows]
+
+    bg_tn_stage<false>(g, smem, 0, 0, 0, Ka, Nb, wid);
+    bg_tn_stage<true>(g, smem, 0, 0, 0, Ka, Nb, wid);
+    bg_tn_stage<true>(g, smem, 0, 1, 0, Ka, Nb, wid);
+    bg_tn_stage<false>(g, smem, 0, 1, 0, Ka, Nb, wid);
+    bg_tn_stage<false>(g, smem, 1, 0, 1, Ka, Nb, wid);
+    bg_tn_stage<true>(g, smem, 1, 0, 1, Ka, Nb, wid);
+    bg_wait_vm<8>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+#define BGT_RD(DST, ADDR, OFF)                                                                                               \
+    {                                                                                                                        \
+        bg_u32x2 lo_, hi_;                                                                                                   \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo_) : "v"(ADDR), "n"(OFF));                               \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi_) : "v"(ADDR), "n"((OFF) + 1024));                      \
+        DST = bg_u32x4t{lo_.x, lo_.y, hi_.x, hi_.y};                                                                         \
+    }
+#define BGT_READ_A(P, HALF)                                                                                                  \
+    BGT_RD(af[0][0], fa[0], (P) * 32768 + (HALF) * BG_HALF) BGT_RD(af[0][1], fa[0], (P) * 32768 + (HALF) * BG_HALF + 8192)                         \
+    BGT_RD(af[1][0], fa[1], (P) * 32768 + (HALF) * BG_HALF) BGT_RD(af[1][1], fa[1], (P) * 32768 + (HALF) * BG_HALF + 8192)                         \
+    BGT_RD(af[2][0], fa[2], (P) * 32768 + (HALF) * BG_HALF) BGT_RD(af[2][1], fa[2], (P) * 32768 + (HALF) * BG_HALF + 8192)                         \
+    BGT_RD(af[3][0], fa[3], (P) * 32768 + (HALF) * BG_HALF) BGT_RD(af[3][1], fa[3], (P) * 32768 + (HALF) * BG_HALF + 8192)
+#define BGT_READ_B(DST, P, HALF)                                                                                             \
+    BGT_RD(DST[0][0], fb[0], (P) * 32768 + (HALF) * BG_HALF) BGT_RD(DST[0][1], fb[0], (P) * 32768 + (HALF) * BG_HALF + 8192)                       \
+    BGT_RD(DST[1][0], fb[1], (P) * 32768 + (HALF) * BG_HALF) BGT_RD(DST[1][1], fb[1], (P) * 32768 + (HALF) * BG_HALF + 8192)
+    // the reads have landed: every fragment register passes through the wait, so that no consumer is scheduled in front of it
+#define BGT_WAIT()                                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]) :: "memory"); \
+    asm volatile("" : "+v"(bf0[0][0]), "+v"(bf0[0][1]), "+v"(bf0[1][0]), "+v"(bf0[1][1]), "+v"(bf1[0][0]), "+v"(bf1[0][1]), "+v"(bf1[1][0]), "+v"(bf1[1][1]));
+#define BGT_MMA(QA, QB, BF, BIAS)                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+                acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i][ks]), __builtin_bit_cast(bf16x8, BF[j][ks]), acc[QA][QB][i][j], 0, 0, 0); \
+    if ((BIAS) && bias_wave) {          /* vector adds behind the MFMAs' issue */                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                      \
+            float t_ = 0.f;                                                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                \
+                    t_ += __uint_as_float(BF[j][ks][e] << 16) + __uint_as_float(BF[j][ks][e] & 0xffff0000u);                 \
+            csum[QB][j] += bsc * t_;                                                                                         \
+        }                                                                                                                    \
+    }                                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);
+#define BGT_PHASE(READS, STAGE, VM, MMA)                                                                                     \
+    READS                                                                                                                    \
+    STAGE                                                                                                                    \
+    bg_wait_vm<VM>();                                                                                                        \
+    __builtin_amdgcn_s_barrier();                                                                                            \
+    BGT_WAIT()                                                                                                               \
+    MMA                                                                                                                      \
+    __builtin_amdgcn_s_barrier();
+#define BGT_TILE(P, t, S0, S1, S2, S3, V0, V1, V2, V3)                                                                       \
+    BGT_PHASE(BGT_READ_A(P, 0) BGT_READ_B(bf0, P, 0), if (S0) bg_tn_stage<true>(g, smem, (P) ^ 1, 1, (t) + 1, Ka, Nb, wid);, V0, BGT_MMA(0, 0, bf0, true)) \
+    BGT_PHASE(BGT_READ_B(bf1, P, 1), if (S1) bg_tn_stage<false>(g, smem, (P) ^ 1, 1, (t) + 1, Ka, Nb, wid);, V1, BGT_MMA(0, 1, bf1, true))                \
+    BGT_PHASE(BGT_READ_A(P, 1), if (S2) bg_tn_stage<false>(g, smem, P, 0, (t) + 2, Ka, Nb, wid);, V2, BGT_MMA(1, 1, bf1, false))                          \
+    BGT_PHASE(, if (S3) bg_tn_stage<true>(g, smem, P, 0, (t) + 2, Ka, Nb, wid);, V3, BGT_MMA(1, 0, bf0, false))
+
+#define BGT_NEXT_SAMPLE() if (brs) { brow += 128; if (brow >= brsT) { brow -= brsT; ++bidx; bsc = brs[min(bidx, (M - 1) / brsT)]; } }
+    int t = 0;
+    for (; t + 4 <= T; t += 2) {
+        BGT_TILE(0, t, true, true, true, true, 8, 8, 8, 8)
+        BGT_TILE(1, t + 1, true, true, true, true, 8, 8, 8, 8)
+        BGT_NEXT_SAMPLE()
+    }
+    BGT_TILE(0, t, true, true, false, false, 8, 8, 6, 4)
+    BGT_TILE(1, t + 1, false, false, false, false, 2, 0, 0, 0)
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef BGT_TILE
+#undef BGT_NEXT_SAMPLE
+#undef BGT_PHASE
+#undef BGT_MMA
+#undef BGT_WAIT
+#undef BGT_READ_A
+#undef BGT_READ_B
+#undef BGT_RD
+    __builtin_amdgcn_s_barrier();
+
+    // the partial tile -> this split's slab: quadrant (a, b) = output rows k0 + 128a + 64wr .. +63, columns n0 + 128b + 32wc .. +31 (one 128-byte
+    // line per row), through a wave-private fp32 stage so that a store instruction writes 8 whole lines
+    constexpr int SLD = 36;
+    float* stage = reinterpret_cast<float*>(smem) + wid * (64 * SLD);
+    float* sl = slab + (size_t)split * sstride;
+#define BGT_EPI(QA, QB)                                                                                                      \
+    {                                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                \
+                    stage[(16 * i + 4 * (lane >> 4) + r) * SLD + 16 * j + (lane & 15)] = acc[QA][QB][i][j][r];               \
+        float* orow = sl + (size_t)(k0 + 128 * (QA) + 64 * wr + (lane >> 3)) * Nb + n0 + 128 * (QB) + 32 * wc + (lane & 7) * 4; \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                                        \
+            *reinterpret_cast<float4*>(orow + (size_t)(8 * q) * Nb) = *reinterpret_cast<const float4*>(stage + ((lane >> 3) + 8 * q) * SLD + (lane & 7) * 4); \
+    }
+    BGT_EPI(0, 0) BGT_EPI(0, 1) BGT_EPI(1, 0) BGT_EPI(1, 1)
+#undef BGT_EPI
+    if (bias_wave) {          // fold the four row groups of a column
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float t_ = csum[b][j];
+                t_ += __shfl_xor(t_, 16, 64);
+                t_ += __shfl_xor(t_, 32, 64);
+                if (lane < 16) sl[(size_t)Ka * Nb + n0 + 128 * b + 32 * wc + 16 * j + lane] = t_;
+            }
+    }
+}
+
+extern int g_nt_big;
+int g_tn_big = 1;
+// rows per M-split of the big weight-gradient kernel (0: the shape is not one it takes)
+int gemm_tn_big_plan(int M, int Ka, int Nb, int* splits_out) {
+    if (!g_nt_big || !g_tn_big || M < 32768 || Ka % 256 != 0 || Nb % 256 != 0 || Ka < 512 || Nb < 512) return 0;
+    const int tiles = (Ka >> 8) * (Nb >> 8);
+    if (tiles > 32) return 0;
+    // as close to one workgroup per CU as whole, even numbers of 64-row K steps allow; a multiple of 8 keeps the XCD-aware (tile, split) order
+    int splits = 0;
+    for (int sp = 256 / tiles; sp >= 8; --sp)
+        if (M % (sp * 128) == 0 && (sp & 7) == 0) { splits = sp; break; }
+    if (!splits || tiles * splits < 160) return 0;
+    *splits_out = splits;
+    return M / splits;
+}
+// returns 1 when the shape is not one this kernel takes; on 0 the caller sums `splits` slabs of stride Ka * Nb + Nb
+int launch_gemm_tn_big(const void* A, const void* B, float* slab, int want_bias, int M, int Ka, int Nb, int* splits_out, const float* brs, int brsT, hipStream_t s) {
+    int splits = 0;
+    const int rps = gemm_tn_big_plan(M, Ka, Nb, &splits);
+    if (rps <= 0) return 1;
+    static bool prepared = false, ok = false;
+    if (!prepared) {
+        prepared = true;
+        ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BG_BUF) == hipSuccess;
+    }
+    if (!ok) return 1;
+    const int tiles = (Ka >> 8) * (Nb >> 8);
+    hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(tiles * splits), dim3(512), 2 * BG_BUF, s, (const bf16*)A, (const bf16*)B, slab, want_bias, M, Ka, Nb, rps, tiles, splits, brs, brsT);
+    *splits_out = splits;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern int g_nt_big;
 static int big_env() { const char* e = getenv("ISHARA_NT_BIG"); return e ? atoi(e) : 1; }
 int g_nt_big = big_env();           // 0: never (A/B runs, ishara_debug_set_nt_big)

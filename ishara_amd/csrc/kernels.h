@@ -113,7 +113,7 @@ bool gemm_nt_as_prologue_ok(int dtA, int dtM, int dtC, int M, int N, int K, int 
 const char* gemm_nt_kernel_name(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea);
 extern int g_force_tn_regstage;   // tests: 1 forces the register-transposing TN kernel
 extern int g_tn_phase;   // 0 GEMM + slab sums, 1 GEMM kernel only, 2 slab sums only
-const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb);
+const char* gemm_tn_kernel_name(int dtA, int dtB, int dtM, int opA, int opB, int M, int Ka, int Nb, bool brs = false);
 
 // weight shadows: Wt[Np][Kp] (transposed) and Wn[Kp2][Np2] (as-is, padded) in dtM
 int launch_make_shadow(int dtM, const float* W, int K, int N, void* Wt, int ldt, void* Wn, int ldn, hipStream_t s);

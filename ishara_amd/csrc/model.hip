@@ -519,7 +519,7 @@ int gemm_wgrad(ishara_model* m, const DenseW& w, const void* A, int dtA, int aop
     }
     g_tn_phase = 1;
     // (the per-sample-affine variant is profiled under its own rocprof name: a different instantiation doing the statistics pass's work too)
-    CKP(m, psa ? "gemm_tn_tr_kernel<0,false,true>" : gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T, nullptr, psa));
+    CKP(m, psa ? "gemm_tn_tr_kernel<0,false,true>" : gemm_tn_kernel_name(dtA, dtB, m->dt, aop, bop, M, w.K, w.N, bias_rowscale != nullptr), by, 2.0 * M * w.N * w.K, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T, nullptr, psa));
     g_tn_phase = 2;
     CKP(m, "reduce_slabs(wgrad)", 0, 0, launch_gemm_tn(dtA, dtB, m->dt, aop, bop, A, dY, m->G(w.w), w.b >= 0 ? m->G(w.b) : nullptr, m->Wf(m->slab), M, w.K, w.N, oa, ob, m->s, ka_valid, nb_valid, bias_rowscale, bias_T, nullptr, psa));
     g_tn_phase = 0;

@@ -167,3 +167,50 @@ def test_project_conv_wgrad_psa_config4_shape():
             if e > worst:
                 worst, worst_name = e, name
     assert worst <= 6e-2, f"worst per-parameter rel-L2 {worst} ({worst_name})"
+
+
+def test_config4_big_tile_gemms_match_small_tile_route():
+    """configs[3]'s shapes at M = B * T = 32768 rows, where the 256 x 256 tile GEMMs of gemm_big.hip take over the dense layers with K, N >= 512
+    (forward / dgrad: gemm_nt_big_kernel; weight gradients incl. the drop-path weighted bias sums: gemm_tn_big_kernel): the same model, batch
+    and dropout seed with the big kernels switched off (ishara_debug_set_nt_big(0): A-stationary + 128 x 128 tile kernels).  The forward
+    accumulations run in the same order over K, so loss and logits agree to bf16 rounding of single outputs; the weight gradients split M
+    differently (fp32 summation order)."""
+    from ishara_amd import _lib
+    lib = _lib.load()
+    kw = dict(dim=512, num_conv_squeeze_blocks=1, num_conv_conform_blocks=1, kernel_sizes=[11, 5, 3], num_conv_per_block=3,
+              num_heads=8, expansion_factor=2, transformer_kernel_size=15, input_shape=(512, 224))
+    b = 64
+    g = np.random.default_rng(33)
+    x = torch.from_numpy(g.standard_normal((b, 512, 224)).astype(np.float32)).cuda()
+    y = np.full((b, 64), 59, np.int64)
+    for i in range(b):
+        n = int(g.integers(8, 32))
+        y[i, :n] = g.integers(0, 59, n)
+    y = torch.from_numpy(y).cuda()
+    m = get_model(**kw, dropout_rate=0.2, dtype="bf16", max_batch=b, seed=0)
+    res = {}
+    try:
+        for on in (0, 1):
+            lib.ishara_debug_set_nt_big(on)
+            l, lg = m.loss_and_gradients(x, y, seed=5)
+            res[on] = (float(l.item()), lg.clone().float(), m.grads.clone())
+    finally:
+        lib.ishara_debug_set_nt_big(1)
+    (l0, lg0, g0), (l1, lg1, g1) = res[0], res[1]
+    assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)
+    assert (lg0 - lg1).abs().max().item() <= 0.15, (lg0 - lg1).abs().max().item()          # logits: a few bf16 roundings through 2 blocks
+    assert torch.isfinite(g1).all()
+    rel = ((g0 - g1).norm() / g0.norm()).item()
+    assert rel <= 2e-2, f"flat gradient rel-L2 between the two routes {rel}"
+    worst, worst_name = 0.0, ""
+    for name, shape, off, trainable in m.entries:
+        if not trainable or name.endswith("/depthwise_conv/bias"):
+            continue
+        n = int(np.prod(shape))
+        a, b_ = g0[off:off + n], g1[off:off + n]
+        den = a.norm().item()
+        if den > 0:
+            e = (a - b_).norm().item() / den
+            if e > worst:
+                worst, worst_name = e, name
+    assert worst <= 6e-2, f"worst per-parameter rel-L2 {worst} ({worst_name})"

@@ -179,6 +179,38 @@ def test_dense_big_tile_kernel(lib, M, K, N, act, with_resid):
     close(outs[1][rows.cuda()], ref, "dense_big", **TOL["bf16"])
 
 
+@pytest.mark.parametrize("M,K,N", [(32768, 512, 512), (32768, 512, 1024), (65536, 1024, 512), (32768, 768, 512)])
+def test_dense_bwd_big_tile_weight_gradient(lib, M, K, N):
+    """The 256 x 256 tile form of the weight-gradient GEMM (gemm_big.hip gemm_tn_big_kernel: K, N >= 512 in whole 256-wide tiles, M >= 32768)
+    against the 128 x 128 tile kernel it replaces there (ishara_debug_set_nt_big(0) switches both big kernels off) and against fp64:
+    dW = x^T dy, db = column sums of dy, accumulated INTO the outputs (they start non-zero).  The two kernels split M differently, so the
+    fp32 sums differ by rounding only."""
+    code, tdt = DT["bf16"]
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(tdt)
+    dy = (torch.randn(M, N, generator=g) * 0.5).to(tdt)
+    W = torch.randn(K, N, generator=g) / K ** 0.5
+    xd, dyd, Wd = x.cuda().contiguous(), dy.cuda().contiguous(), dev(W)
+    sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
+    scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
+    outs = {}
+    try:
+        for on in (0, 1):
+            lib.ishara_debug_set_nt_big(on)
+            dW = torch.full((K, N), 0.25, device="cuda"); db = torch.full((N,), -0.5, device="cuda")
+            _lib.check(lib.ishara_op_dense_bwd(code, _lib.ptr(xd), _lib.ptr(Wd), _lib.ptr(dyd), None, _lib.ptr(dW), _lib.ptr(db), M, K, N, scp, stream()))
+            torch.cuda.synchronize()
+            outs[on] = (dW.cpu(), db.cpu())
+    finally:
+        lib.ishara_debug_set_nt_big(1)
+    refW = x.double().t() @ dy.double() + 0.25
+    refb = dy.double().sum(0) - 0.5
+    for on in (0, 1):
+        close(outs[on][0], refW, f"dW big={on}", rtol=2e-4, atol=2e-3 * (M / 32768) ** 0.5)
+        close(outs[on][1], refb, f"db big={on}", rtol=2e-4, atol=2e-3 * (M / 32768) ** 0.5)
+    close(outs[1][0], outs[0][0].double(), "dW big vs tile", rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,Cc", [(100, 64), (1000, 256), (77, 512)])
 def test_layernorm(lib, dt, M, Cc):
