@@ -21,7 +21,8 @@
 //   * epilogue: four passes of 32 rows x 64 columns per wave through a wave-private fp32 LDS stage, whole 128-byte lines per row, the shared fused
 //     epilogue arithmetic (gemm_epi.h: bias, activation, dropout, row scale, act', residual, saved pre-activation); all its loads before its first store.
 //
-// Shapes: M % 256 == 0, N % 256 == 0, K % 128 == 0 (an even number of K steps), EPI_STD, no operand prologue; everything else stays on gemm_as.hip.
+// Shapes: M % 256 == 0, N % 256 == 0, K % 128 == 0 (an even number of K steps), EPI_STD or the plain QKV head split, no operand prologue;
+// everything else stays on gemm_as.hip / the 128 x 128 tile kernels.
 #include <type_traits>
 #include <cstdlib>
 #include "kernels.h"
@@ -187,6 +188,17 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const bf16* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) er.bias[e] = ea.bias ? ea.bias[ncol + e] : 0.f;
     const float rs0 = ea.rowscale ? ea.rowscale[m0 / ea.T] : 1.f;          // the tile's 256 rows lie in one sample (launcher: T % 256 == 0)
+    // QKV head split: q and k leave through the row chunks above; the v columns are written TRANSPOSED ([B, H, dh, T]) by a sweep over the stage
+    // with a lane per column (8 consecutive frames = 16 bytes per store).  Its bias is read here, in front of the first store.
+    const int vcol = n0 + 64 * wc + lane;
+    int vh = 0, vpart = 0, vi = 0;
+    float vbias = 0.f;
+    if (ea.mode == EPI_QKV) {
+        const int d = ea.H * ea.dh;
+        if (ea.head_major) { vh = vcol / (3 * ea.dh); const int w = vcol - vh * 3 * ea.dh; vpart = w / ea.dh; vi = w - vpart * ea.dh; }
+        else { vpart = vcol / d; const int w = vcol - vpart * d; vh = w / ea.dh; vi = w - vh * ea.dh; }
+        vbias = ea.bias ? ea.bias[vcol] : 0.f;
+    }
     const TC* opsrc = reinterpret_cast<const TC*>(ea.resid ? ea.resid : ea.aux);      // at most one of the two (launcher)
     const bool has_op = ea.resid != nullptr || ea.dact != DACT_NONE;
     typedef __attribute__((ext_vector_type(4))) unsigned int bg_u32x4;
@@ -219,6 +231,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const bf16* __restr
             }                                                                                                                \
         }                                                                                                                    \
         er.finish(stage + (lane >> 3) * SLD + (lane & 7) * 8, 8 * SLD, M, N, ea, C);                                         \
+        if (ea.mode == EPI_QKV && vpart == 2) {                                                                              \
+            _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                                               \
+                const int mb = m0 + 64 * wr + 128 * QA + 32 * H + 8 * rg;                                                    \
+                float v8[8];                                                                                                 \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) v8[e] = stage[(8 * rg + e) * SLD + lane] + vbias;              \
+                const int bb = mb / ea.T, tt_ = mb - bb * ea.T;                                                              \
+                store8(reinterpret_cast<TC*>(ea.vt) + ((size_t)(bb * ea.H + vh) * ea.dh + vi) * ea.T + tt_, v8);             \
+            }                                                                                                                \
+        }                                                                                                                    \
     }
     BG_EPI(0) BG_EPI(1) BG_EPI(2) BG_EPI(3)
 #undef BG_EPI
@@ -459,7 +480,7 @@ int g_nt_big = big_env();           // 0: never (A/B runs, ishara_debug_set_nt_b
 
 bool gemm_nt_big_applicable(int dtA, int dtM, int dtC, int op, const void* A, int M, int N, int K, int ldb, const EpiArgs& ea) {
     return g_nt_big != 0 && dtA == DT_BF16 && dtM == DT_BF16 && dtC == DT_BF16 && op == OP_NONE && M >= 32768 && M % 256 == 0 && N % 256 == 0 && N >= 512 &&
-           K >= 512 && K % 128 == 0 && ldb % 8 == 0 && ldb >= K && ((uintptr_t)A) % 16 == 0 && ea.mode == EPI_STD && !ea.ln_gamma && !ea.pa_P && !ea.ldc && !ea.n_valid && !ea.dbg && !ea.addtab &&
+           K >= 512 && K % 128 == 0 && ldb % 8 == 0 && ldb >= K && ((uintptr_t)A) % 16 == 0 && (ea.mode == EPI_STD || (ea.mode == EPI_QKV && ea.dh % 8 == 0 && ea.T % 8 == 0 && !ea.pre_out && !ea.act && !ea.drop.thr && !ea.rowscale && !ea.resid && ea.dact == DACT_NONE)) && !ea.ln_gamma && !ea.pa_P && !ea.ldc && !ea.n_valid && !ea.dbg && !ea.addtab &&
            !(ea.resid && ea.dact != DACT_NONE) && (!ea.rowscale || (ea.T > 0 && ea.T % 256 == 0));
 }
 
