@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""HBM read bytes of single weight-gradient launches under the workgroup-count variants (run under rocprofv3 --pmc FETCH_SIZE, then
-`tools/tn_traffic.py --parse <counter_collection.csv>`): prints, per launch in dispatch order, the fetched bytes (x2, gfx950 wide reads)
-next to the algorithmic M x (K + N) x 2."""
+"""HBM read bytes of single weight-gradient launches, 128 x 128 tile kernel vs the 256 x 256 tile kernel (run under rocprofv3 --pmc FETCH_SIZE, then
+`tools/tn_traffic.py --parse <counter_collection.csv> gpurun_out/tn_traffic_plan.txt`): prints, per launch in dispatch order, the fetched bytes
+(x2, gfx950 wide reads) next to the algorithmic M x (K + N) x 2.  Without the profiler it prints the time per launch incl. the slab sums.
+(profiles/r3_tn_traffic_pacing.txt was made with an earlier form of this script on a build that paced the sibling workgroups: DESIGN.md 7c.)"""
 import sys
 if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     import csv
-    rows = [r for r in csv.DictReader(open(sys.argv[2])) if r["Counter_Name"] == "FETCH_SIZE" and "gemm_tn_tr" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(sys.argv[2])) if r["Counter_Name"] == "FETCH_SIZE" and ("gemm_tn_tr" in r["Kernel_Name"] or "gemm_tn_big" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     plan = [l.split() for l in open(sys.argv[3])]
     for r, p in zip(rows, plan):
@@ -19,7 +20,7 @@ from ishara_amd import _lib
 lib = _lib.load()
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = [(262144, 512, 512), (262144, 512, 1024), (98304, 256, 256), (98304, 256, 512), (98304, 256, 768)]
-V = {"nopace": 1 << 17, "g1l1": 2 << 17, "g1l2": (2 << 17) | (2 << 21), "g2l1": 3 << 17, "g2l2": (3 << 17) | (2 << 21), "g4l1": 5 << 17}
+V = {"tile128": 0, "tile256": 1}          # ishara_debug_set_nt_big: the 128 x 128 tile kernel / the 256 x 256 tile kernel where it applies
 plan = open("gpurun_out/tn_traffic_plan.txt", "w")
 for (M, K, N) in SHAPES:
     x = torch.randn(M, K, device="cuda").bfloat16(); dy = torch.randn(M, N, device="cuda").bfloat16()
@@ -28,7 +29,7 @@ for (M, K, N) in SHAPES:
     sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
     scp = C.c_void_p(sc.data_ptr() + (-sc.data_ptr()) % 256)
     for name, bits in V.items():
-        lib.ishara_debug_force_regstage(bits)
+        lib.ishara_debug_set_nt_big(bits)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(3):
             if i == 1: e0.record()
@@ -36,6 +37,6 @@ for (M, K, N) in SHAPES:
             plan.write(f"{name} {M} {K} {N}\n")
         e1.record(); torch.cuda.synchronize()
         print(f"{name:8s} M{M} K{K} N{N}: {e0.elapsed_time(e1)*1e3/2:.0f} us (wgrad + slab sums)", flush=True)
-    lib.ishara_debug_force_regstage(0)
+    lib.ishara_debug_set_nt_big(1)
     del x, dy, sc
 plan.close()
