@@ -6,7 +6,8 @@ from ishara_amd import _lib
 lib = _lib.load()
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-for (K, N) in [(1024, 512), (512, 1024), (512, 512), (512, 2048), (2048, 512)]:
+SHAPES = [(1024, 512), (512, 1024), (512, 512), (512, 2048), (2048, 512)] if len(sys.argv) < 3 else [tuple(int(v) for v in a.split(',')) for a in sys.argv[2:]]
+for (K, N) in SHAPES:
     x = torch.randn(M, K, device="cuda").bfloat16(); W = torch.randn(K, N, device="cuda") / K ** 0.5; b = torch.zeros(N, device="cuda")
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     sc = torch.empty(int(lib.ishara_op_scratch_bytes(M, K, N)) + 256, dtype=torch.uint8, device="cuda")
